@@ -1,0 +1,171 @@
+/*
+ * flyhip.h — C ABI of libflyhip.so, the MI355X (gfx950) replacement for the one hot path of
+ * petim0/fly_bProject: the vectorised Fly environment step and the PPO rollout/update math.
+ *
+ * What this boundary replaces.  The reference has no FFI of its own; its de-facto native
+ * boundary is the Isaac Gym tensor API that fly.py drives with raw device pointers
+ * (gymtorch.unwrap_tensor):
+ *     acquire_*_tensor / wrap_tensor            fly.py:380-391
+ *     refresh_*_tensor                          fly.py:401-403
+ *     set_dof_position_target_tensor            fly.py:657
+ *     set_actor_root_state_tensor_indexed,
+ *     set_dof_state_tensor_indexed              fly.py:462-468
+ *     simulate + fetch_results                  fly.py:484-485
+ * plus the torch op chains in fly.py:626-657, :685-805 and ppo.py:157-237.  Each entry point
+ * below cites the reference lines it stands in for.
+ *
+ * Conventions
+ *   - extern "C", plain C types only.  Every pointer is a DEVICE pointer owned by the caller
+ *     (torch-ROCm allocations); the library never allocates or frees caller tensors.
+ *   - Every launch takes a hipStream_t (passed as void*); nothing synchronises the host.
+ *     All entry points are hipGraph-capturable.
+ *   - Return 0 on success, negative FLY_E_* on error; fly_last_error() returns a
+ *     thread-local message.  No exceptions cross the boundary.
+ *   - Not re-entrant per handle: callers serialise calls on one handle.
+ *
+ * HBM layout ("env-minor": the env index is the fastest-varying one, so lane i of a wave
+ * touches env i and every field access is one coalesced 256-B line per wave)
+ *   root      f32 [13][N]   pos xyz | quat xyzw | linvel xyz | angvel xyz   (fly.py:95-100)
+ *   dof_pos   f32 [18][N]   joint angles, sim DoF order (see FlyConfig.dof_*)
+ *   dof_vel   f32 [18][N]
+ *   targets   f32 [18][N]   PD position targets = scaled actions (fly.py:636, the reference's
+ *                           `self.actions`)
+ *   contact   f32 [11][3][N] net contact force of the 11 tracked bodies: 0-4 abdomen
+ *                           A1A2,A3,A4,A5,A6; 5-10 leg tips LF,LH,LM,RF,RH,RM (fly.py:299-300)
+ *   pot, prev_pot f32 [N]   potentials (fly.py:121-123)
+ *   reset, progress i64 [N] reference dtypes kept (fly.py:175-177)
+ * Row-major (GEMM operand) tensors
+ *   actions   f32 [N][18]   policy output in [-1,1]
+ *   obs       f32 [N][73]   observation rows (fly.py:799-803)
+ *   reward    f32 [N]
+ */
+#ifndef FLYHIP_H
+#define FLYHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLY_NUM_DOF 18
+#define FLY_NUM_OBS 73
+#define FLY_NUM_LEGS 6
+#define FLY_NUM_ABDOMEN 5
+#define FLY_NUM_CONTACT 11
+#define FLY_ROOT_DIM 13
+
+#define FLY_OK 0
+#define FLY_E_ARG (-1)      /* bad argument (null pointer, bad size, misalignment) */
+#define FLY_E_HIP (-2)      /* a HIP runtime call failed */
+#define FLY_E_CONFIG (-3)   /* inconsistent FlyConfig */
+
+/* GAE mode flags for ppo_td_gae (ppo.py:157-171 quirks). */
+#define PPO_GAE_COMPAT 0        /* reference semantics: done mask broadcast from a [N] row, no reset of the recurrence */
+#define PPO_GAE_DONE_PER_STEP 1 /* done is [T][N] instead of [N] */
+#define PPO_GAE_MASK_RECURRENCE 2 /* adv_t = delta_t + gamma*lambda*done_t*adv_{t+1} (non-reference) */
+
+/*
+ * FlyConfig: everything fly.py hard-codes in Fly.__init__ / create_sim / create_envs
+ * (fly.py:16-51, :147-167, :220-228) plus the parameters of the build-defined rigid-body
+ * model that stands in for gym.simulate() (DESIGN.md "FlyDyn").  Plain floats/ints, 4-byte
+ * aligned, no padding.
+ */
+typedef struct FlyConfig {
+    int32_t num_envs;
+    int32_t substeps;            /* fly.py:154 (15); flyLowGrav.py:151 (2) */
+    int32_t reset_after_sim;     /* 0: reset before simulate (fly.py:660); 1: after (flyLowGrav.py:661-663) */
+    int32_t reward_mode;         /* 0: standing (fly.py:750); 1: walking (fly.py:747-748, commented out upstream) */
+    int32_t max_episode_length;  /* fly.py:34 */
+    float dt;                    /* fly.py:16 */
+    float gravity;               /* fly.py:151 (z component) */
+    /* PD position drive, fly.py:224-228 */
+    float kp, kd, effort, vmax;
+    float joint_inertia;         /* build-defined */
+    /* root rigid body, build-defined (URDF total mass 1e-3) */
+    float mass;
+    float inertia[3];
+    /* contact model, build-defined; mu = fly.py:39-40 */
+    float kc, cdamp, mu, cvisc;
+    float lin_damp, ang_damp;
+    /* leg kinematics, build-defined */
+    float femur_len, tibia_len, alpha0, beta0;
+    float dof_lo[FLY_NUM_DOF];   /* URDF joint limits, sim DoF order */
+    float dof_hi[FLY_NUM_DOF];
+    float dof_pose[FLY_NUM_DOF]; /* pose_default.yaml, rad */
+    float leg_attach[FLY_NUM_LEGS][3];
+    float leg_azimuth[FLY_NUM_LEGS];
+    float leg_sigma[FLY_NUM_LEGS];
+    float abdomen_pts[FLY_NUM_ABDOMEN][3];
+    /* task constants, fly.py:33-51, :134 */
+    float start_height;
+    float target[3];
+    float dof_vel_scale;
+    float up_weight;
+    float heading_weight;
+    float actions_cost_scale;
+    float energy_cost_scale;
+    float joints_at_limit_cost_scale;
+    float death_cost;
+    float termination_height;
+    float termination_height_up;
+} FlyConfig;
+
+typedef struct FlyEnv* FlyHandle;
+
+/* Device-pointer bundle of one environment batch (layouts: file header). */
+typedef struct FlyBuffers {
+    float* root;        /* [13][N] */
+    float* dof_pos;     /* [18][N] */
+    float* dof_vel;     /* [18][N] */
+    float* targets;     /* [18][N] */
+    float* contact;     /* [11][3][N] */
+    float* pot;         /* [N] */
+    float* prev_pot;    /* [N] */
+    float* obs;         /* [N][73] */
+    float* reward;      /* [N] */
+    int64_t* reset;     /* [N] */
+    int64_t* progress;  /* [N] */
+} FlyBuffers;
+
+const char* fly_last_error(void);
+int fly_abi_version(void);
+
+/* Stands in for acquire_gym/create_sim/prepare_sim (fly.py:57-59, :139): validates and
+ * uploads the config.  No tensor memory is allocated. */
+int fly_create(const FlyConfig* cfg, FlyHandle* out);
+int fly_destroy(FlyHandle h);
+
+/* One whole Fly.step (fly.py:624-681) in ONE launch: K1 scale -> K2 masked reset -> K3
+ * substepped integrator -> K4 obs pack -> progress+=1 -> K5 reward/done pack (K2/K3 swapped
+ * when cfg.reset_after_sim).  `actions` is f32 [N][18]. */
+int fly_step(FlyHandle h, const float* actions, const FlyBuffers* b, void* stream);
+
+/* Unfused pieces, one launch each (parity tests, and callers that interleave their own work). */
+/* fly.py:626-657 + isaacgym scale(): targets[j][e] = 0.5*(a+1)*(hi-lo)+lo */
+int fly_scale_actions(FlyHandle h, const float* actions, float* targets, void* stream);
+/* fly.py:446-480: masked reset of flagged envs; clears reset/progress. */
+int fly_reset_masked(FlyHandle h, const FlyBuffers* b, void* stream);
+/* fly.py:482-485 (gym.simulate + fetch_results): `substeps` semi-implicit Euler substeps. */
+int fly_integrate(FlyHandle h, const FlyBuffers* b, void* stream);
+/* fly.py:397-411, :771-805: observation rows + potentials. */
+int fly_pack_obs(FlyHandle h, const FlyBuffers* b, void* stream);
+/* fly.py:678 + :413-443, :685-768: progress+=1 (when add_progress), reward, done mask. */
+int fly_pack_reward(FlyHandle h, const FlyBuffers* b, int add_progress, void* stream);
+
+/* ppo.py:213-220: act = mu + sqrt(var)*eps; logp of the UNCLIPPED act; act_out = clip(act,-1,1).
+ * mu,eps,act_out f32 [n][18]; var f32 [18]; logp_out f32 [n]. */
+int ppo_sample_logprob(const float* mu, const float* var, const float* eps,
+                       float* act_out, float* logp_out, int64_t n, void* stream);
+
+/* ppo.py:157-171: target = r + gamma*v_next*done; delta = target - v;
+ * adv_t = gamma*lambda*adv_{t+1} + delta_t.  reward,v,v_next,target_out,adv_out f32 [T][N];
+ * done f32 [N] (or [T][N] with PPO_GAE_DONE_PER_STEP). */
+int ppo_td_gae(const float* reward, const float* v, const float* v_next, const float* done,
+               float gamma, float lambda, int64_t T, int64_t N,
+               float* target_out, float* adv_out, int mode_flags, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLYHIP_H */
