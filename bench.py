@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the whole PPO loop (rollout + update) on N MI355X.
+
+One "step" (--steps K) is ONE PPO iteration on every rank: T = 16*(40960//num_envs) env steps of
+`num_envs` envs (policy forward, sample, fused env step, rollout store) followed by the update
+(critic pass + TD/GAE + 5 epochs x 15 minibatches of 40 960 samples, Adam).  At the default
+8192 envs/GPU that is 80 env steps = 655 360 env-steps per rank per step (ppo.py:118-122).
+Ranks shard envs with no data-path collective except the per-optimizer-step gradient all-reduce
+(scaling: weak).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FUSED_STEP_BYTES_PER_ENV = 800     # fused step K1-K5, algorithmic bytes per env-step
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3, help="PPO iterations timed")
+    ap.add_argument("--warmup", type=int, default=1, help="PPO iterations untimed")
+    ap.add_argument("--num_envs", type=int, default=8192, help="envs per GPU")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--kernel_reps", type=int, default=200)
+    return ap.parse_args()
+
+
+def make_args(n, **kw):
+    import types
+    d = dict(sim_device="cuda:0", num_envs=n, headless=True, testing=False, save=False, load=False,
+             record=False, save_freq=100, save_path=None, load_path=None, seed=0, rank=0, world_size=1,
+             variant="bigGrav", reward="standing")
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def kernel_roofline(num_envs, reps):
+    """Average duration of the dominant env kernel (fly_step, one launch per env step), measured
+    with HIP events on the stream it is launched on (torch's current stream)."""
+    from fly_bproject_amd.fly import Fly
+    env = Fly(make_args(num_envs))
+    a = torch.zeros(num_envs, 18, device="cuda:0").uniform_(-1, 1)
+    for _ in range(20):
+        env.step(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        env.step(a)
+    e1.record()
+    torch.cuda.synchronize()
+    dur_s = e0.elapsed_time(e1) * 1e-3 / reps
+    env.exit()
+    achieved = FUSED_STEP_BYTES_PER_ENV * num_envs / dur_s / 1e9
+    return {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(achieved / 8000.0, 5), "traffic": None, "kernel": "fly_kernel<63> (fly_step)",
+            "avg_launch_us": round(dur_s * 1e6, 3),
+            "algorithmic_bytes_per_launch": FUSED_STEP_BYTES_PER_ENV * num_envs}
+
+
+def cpu_baseline(num_envs):
+    """The oracle ("port") timed on the host cores on a bounded sample of the same workload:
+    `S` env steps of num_envs envs (C oracle, OpenMP over envs, + torch-CPU policy forward and
+    sampling) and `M` PPO minibatch steps of 40 960 samples + the critic pass over 2*40 960 rows,
+    extrapolated to one full iteration (T env steps, 2*T*N critic rows, 75 minibatch steps)."""
+    import numpy as np
+    from oracle import oracle as O
+    from oracle import ppo_oracle as PO
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    T = 16 * (40960 // num_envs)
+    cfg = O.default_config(num_envs)
+    s = O.EnvState(num_envs)
+    net = PO.OracleNet()
+    var = torch.full((18,), 0.2)
+    rng = np.random.default_rng(0)
+    S, M = 24, 6
+    obs = torch.zeros(num_envs, 73)
+    O.env_step(cfg, s, np.zeros((num_envs, 18), np.float32))      # warm caches / threads
+    t0 = time.perf_counter()
+    for _ in range(S):
+        with torch.no_grad():
+            mu = net.pi(obs).numpy()
+        eps = rng.standard_normal((num_envs, 18)).astype(np.float32)
+        act, _ = O.sample_logprob(mu, var.numpy(), eps)
+        O.env_step(cfg, s, act)
+        obs = torch.from_numpy(s.obs.copy())
+    t_step = (time.perf_counter() - t0) / S
+    mb = 40960
+    x = torch.randn(mb, 73); a = torch.rand(mb, 18) * 2 - 1
+    olp = torch.randn(mb); tg = torch.randn(mb, 1); adv = torch.randn(mb, 1)
+    optim = torch.optim.Adam(net.parameters(), lr=1e-3)
+    t0 = time.perf_counter()
+    for _ in range(M):
+        loss = PO.minibatch_loss(net, x, a, olp, tg, adv, var)
+        optim.zero_grad(); loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+        optim.step()
+    t_mb = (time.perf_counter() - t0) / M
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        net.v(torch.randn(2 * mb, 73))
+    t_v = (time.perf_counter() - t0) / (2 * mb)
+    t_gae0 = time.perf_counter()
+    O.td_gae(np.zeros((T, num_envs), np.float32), np.zeros((T, num_envs), np.float32),
+             np.zeros((T, num_envs), np.float32), np.ones(num_envs, np.float32))
+    t_gae = time.perf_counter() - t_gae0
+    t_iter = T * t_step + 2 * T * num_envs * t_v + t_gae + 75 * t_mb
+    return {"value": round(T * num_envs / t_iter, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d env steps of %d envs (C oracle, OpenMP over envs, torch-CPU policy) + %d PPO "
+                      "minibatch steps of 40960 samples + critic pass over %d rows, extrapolated to one "
+                      "iteration (T=%d, 75 optimizer steps)" % (S, num_envs, M, 2 * mb, T),
+            "rollout_env_steps_per_s": round(num_envs / t_step, 1)}
+
+
+def main():
+    a = parse()
+    from fly_bproject_amd.dist import broadcast_parameters, init_from_env
+    from fly_bproject_amd.ppo import PPO
+
+    rank, local_rank, world = init_from_env("cuda")
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    torch.manual_seed(0)
+    args = make_args(a.num_envs, sim_device=dev, rank=rank, world_size=world)
+    with quiet():
+        agent = PPO(args)
+    broadcast_parameters(agent.net)
+    T = agent.rollout_size
+
+    def iteration():
+        with quiet():
+            for _ in range(T):
+                agent.run()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        iteration()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        iteration()
+    fence()
+    elapsed = time.perf_counter() - t0
+    # rollout-only rate (no update) for the breakdown
+    agent.args.testing = True
+    fence()
+    r0 = time.perf_counter()
+    iteration()
+    fence()
+    rollout_s = time.perf_counter() - r0
+    agent.args.testing = False
+    if world > 1:
+        tt = torch.tensor([elapsed, rollout_s], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, rollout_s = float(tt[0]), float(tt[1])
+    assert agent.optim_step == 75 * (a.warmup + a.steps), agent.optim_step
+    finite = all(torch.isfinite(p).all().item() for p in agent.net.parameters())
+    agent.exit()
+
+    if rank == 0:
+        env_steps = world * a.num_envs * T * a.steps
+        line = {
+            "metric": "env-steps/sec (PPO rollout + update), %d envs per GPU" % a.num_envs,
+            "value": round(env_steps / elapsed, 1), "unit": "env-steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "fly_ppo_iteration_%denvs_T%d" % (a.num_envs, T),
+                       "num_envs_per_gpu": a.num_envs, "rollout_size": T, "optimizer_steps_per_iteration": 75,
+                       "minibatch_samples": agent.mini_chunk_size * a.num_envs, "variant": "bigGrav",
+                       "parallelism": "dp%d" % world},
+            "rollout_only_env_steps_per_s": round(world * a.num_envs * T / rollout_s, 1),
+            "params_finite": finite,
+        }
+        line["roofline"] = kernel_roofline(a.num_envs, a.kernel_reps)
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.num_envs)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,74 @@
+"""ctypes binding of libflyhip.so (include/flyhip.h).  Fails loudly: no library, no product."""
+import ctypes as C
+import os
+
+from .params import FlyParams
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libflyhip.so")
+_lib = None
+
+
+class FlyHipError(RuntimeError):
+    pass
+
+
+class FlyBuffers(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("root", "dof_state", "targets", "contact", "pot", "prev_pot",
+                                          "obs", "reward", "reset", "progress")]
+
+
+# name -> argtypes; every entry point returns int except fly_last_error
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+SYMBOLS = {
+    "fly_abi_version": [],
+    "fly_create": [C.POINTER(FlyParams), C.POINTER(_P)],
+    "fly_destroy": [_P],
+    "fly_step": [_P, _P, C.POINTER(FlyBuffers), _P],
+    "fly_scale_actions": [_P, _P, _P, _P],
+    "fly_reset_masked": [_P, C.POINTER(FlyBuffers), _P],
+    "fly_integrate": [_P, C.POINTER(FlyBuffers), _P],
+    "fly_pack_obs": [_P, C.POINTER(FlyBuffers), _P],
+    "fly_pack_reward": [_P, C.POINTER(FlyBuffers), _I, _P],
+    "ppo_sample_logprob": [_P, _P, _P, _P, _P, _L, _P],
+    "ppo_td_gae": [_P, _P, _P, _P, _F, _F, _L, _L, _P, _P, _I, _P],
+}
+
+
+def build(verbose=False):
+    """Compile libflyhip.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FlyHipError(
+            "libflyhip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C fly_bproject_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.fly_last_error.restype = C.c_char_p
+    lib.fly_last_error.argtypes = []
+    for name, argtypes in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().fly_last_error()
+        raise FlyHipError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

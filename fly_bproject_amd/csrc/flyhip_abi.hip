@@ -1,0 +1,156 @@
+// flyhip_abi.hip — the extern "C" surface declared in include/flyhip.h.
+// Argument checking, handle lifetime and error strings live here; kernels live in fly_env.hip
+// and ppo_kernels.hip.  Nothing here synchronises the host or allocates caller tensors.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <new>
+#include "flyhip.h"
+
+extern "C" hipError_t flyhip_launch_env(int phases, const FlyConfig* dcfg, int n, const float* actions,
+                                        const FlyBuffers* b, void* stream);
+extern "C" hipError_t flyhip_launch_sample_logprob(const float* mu, const float* var, const float* eps,
+                                                   float* act_out, float* logp_out, int64_t n, void* stream);
+extern "C" hipError_t flyhip_launch_td_gae(const float* reward, const float* v, const float* v_next,
+                                           const float* done, float gamma, float lambda, int64_t T, int64_t N,
+                                           float* target_out, float* adv_out, int mode, void* stream);
+
+struct FlyEnv {
+    FlyConfig host;
+    FlyConfig* dev;
+};
+
+namespace {
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what)
+{
+    return fail(FLY_E_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+enum : int { PH_SCALE = 1, PH_RESET = 2, PH_INTEGRATE = 4, PH_OBS = 8, PH_REWARD = 16, PH_PROGRESS = 32 };
+
+int check_buffers(const FlyBuffers* b, int phases)
+{
+    if (!b) return fail(FLY_E_ARG, "FlyBuffers is null");
+    const bool need_root = phases & (PH_RESET | PH_INTEGRATE | PH_OBS | PH_REWARD);
+    const bool need_dof = phases & (PH_RESET | PH_INTEGRATE | PH_OBS);
+    const bool need_tgt = phases & (PH_SCALE | PH_INTEGRATE | PH_OBS | PH_REWARD);
+    const bool need_con = phases & (PH_INTEGRATE | PH_OBS | PH_REWARD);
+    const bool need_pot = phases & (PH_RESET | PH_OBS | PH_REWARD);
+    const bool need_obs = phases & (PH_OBS | PH_REWARD);
+    const bool need_flags = phases & (PH_RESET | PH_REWARD | PH_PROGRESS);
+    if (need_root && !b->root) return fail(FLY_E_ARG, "root is null");
+    if (need_dof && !b->dof_state) return fail(FLY_E_ARG, "dof_state is null");
+    if (need_tgt && !b->targets) return fail(FLY_E_ARG, "targets is null");
+    if (need_con && !b->contact) return fail(FLY_E_ARG, "contact is null");
+    if (need_pot && (!b->pot || !b->prev_pot)) return fail(FLY_E_ARG, "pot/prev_pot is null");
+    if (need_obs && !b->obs) return fail(FLY_E_ARG, "obs is null");
+    if (need_obs && ((uintptr_t)b->obs & 3)) return fail(FLY_E_ARG, "obs must be 4-byte aligned");
+    if ((phases & PH_REWARD) && !b->reward) return fail(FLY_E_ARG, "reward is null");
+    if (need_flags && (!b->reset || !b->progress)) return fail(FLY_E_ARG, "reset/progress is null");
+    return FLY_OK;
+}
+
+int launch(FlyHandle h, int phases, const float* actions, const FlyBuffers* b, void* stream)
+{
+    if (!h) return fail(FLY_E_ARG, "handle is null");
+    if ((phases & PH_SCALE) && !actions) return fail(FLY_E_ARG, "actions is null");
+    int rc = check_buffers(b, phases);
+    if (rc) return rc;
+    hipError_t e = flyhip_launch_env(phases, h->dev, h->host.num_envs, actions, b, stream);
+    if (e != hipSuccess) return hip_fail(e, "fly env kernel launch");
+    return FLY_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char* fly_last_error(void) { return g_err; }
+int fly_abi_version(void) { return 1; }
+
+int fly_create(const FlyConfig* cfg, FlyHandle* out)
+{
+    if (!cfg || !out) return fail(FLY_E_ARG, "fly_create: null argument");
+    if (cfg->num_envs <= 0) return fail(FLY_E_CONFIG, "num_envs must be > 0 (got %d)", cfg->num_envs);
+    if (cfg->substeps <= 0 || cfg->substeps > 1024) return fail(FLY_E_CONFIG, "substeps out of range (%d)", cfg->substeps);
+    if (!(cfg->dt > 0.0f)) return fail(FLY_E_CONFIG, "dt must be > 0");
+    if (!(cfg->mass > 0.0f) || !(cfg->joint_inertia > 0.0f)) return fail(FLY_E_CONFIG, "mass / joint_inertia must be > 0");
+    for (int i = 0; i < 3; ++i)
+        if (!(cfg->inertia[i] > 0.0f)) return fail(FLY_E_CONFIG, "inertia[%d] must be > 0", i);
+    for (int j = 0; j < FLY_NUM_DOF; ++j)
+        if (!(cfg->dof_hi[j] > cfg->dof_lo[j])) return fail(FLY_E_CONFIG, "dof limits of joint %d are not ordered", j);
+    if (cfg->reward_mode != 0 && cfg->reward_mode != 1) return fail(FLY_E_CONFIG, "reward_mode must be 0 or 1");
+    FlyEnv* h = new (std::nothrow) FlyEnv;
+    if (!h) return fail(FLY_E_ARG, "out of host memory");
+    h->host = *cfg;
+    h->dev = nullptr;
+    hipError_t e = hipMalloc((void**)&h->dev, sizeof(FlyConfig));
+    if (e != hipSuccess) { delete h; return hip_fail(e, "hipMalloc(FlyConfig)"); }
+    e = hipMemcpy(h->dev, cfg, sizeof(FlyConfig), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(h->dev); delete h; return hip_fail(e, "hipMemcpy(FlyConfig)"); }
+    *out = h;
+    return FLY_OK;
+}
+
+int fly_destroy(FlyHandle h)
+{
+    if (!h) return fail(FLY_E_ARG, "handle is null");
+    hipError_t e = hipFree(h->dev);
+    delete h;
+    if (e != hipSuccess) return hip_fail(e, "hipFree(FlyConfig)");
+    return FLY_OK;
+}
+
+int fly_step(FlyHandle h, const float* actions, const FlyBuffers* b, void* stream)
+{
+    return launch(h, PH_SCALE | PH_RESET | PH_INTEGRATE | PH_OBS | PH_PROGRESS | PH_REWARD, actions, b, stream);
+}
+
+int fly_scale_actions(FlyHandle h, const float* actions, float* targets, void* stream)
+{
+    FlyBuffers b = {};
+    b.targets = targets;
+    return launch(h, PH_SCALE, actions, &b, stream);
+}
+
+int fly_reset_masked(FlyHandle h, const FlyBuffers* b, void* stream) { return launch(h, PH_RESET, nullptr, b, stream); }
+int fly_integrate(FlyHandle h, const FlyBuffers* b, void* stream) { return launch(h, PH_INTEGRATE, nullptr, b, stream); }
+int fly_pack_obs(FlyHandle h, const FlyBuffers* b, void* stream) { return launch(h, PH_OBS, nullptr, b, stream); }
+int fly_pack_reward(FlyHandle h, const FlyBuffers* b, int add_progress, void* stream)
+{
+    return launch(h, add_progress ? (PH_REWARD | PH_PROGRESS) : PH_REWARD, nullptr, b, stream);
+}
+
+int ppo_sample_logprob(const float* mu, const float* var, const float* eps, float* act_out,
+                       float* logp_out, int64_t n, void* stream)
+{
+    if (!mu || !var || !eps || !act_out || !logp_out) return fail(FLY_E_ARG, "ppo_sample_logprob: null pointer");
+    if (n <= 0) return fail(FLY_E_ARG, "ppo_sample_logprob: n must be > 0");
+    hipError_t e = flyhip_launch_sample_logprob(mu, var, eps, act_out, logp_out, n, stream);
+    if (e != hipSuccess) return hip_fail(e, "ppo_sample_logprob launch");
+    return FLY_OK;
+}
+
+int ppo_td_gae(const float* reward, const float* v, const float* v_next, const float* done,
+               float gamma, float lambda, int64_t T, int64_t N, float* target_out, float* adv_out,
+               int mode_flags, void* stream)
+{
+    if (!reward || !v || !v_next || !done || !target_out || !adv_out) return fail(FLY_E_ARG, "ppo_td_gae: null pointer");
+    if (T <= 0 || N <= 0) return fail(FLY_E_ARG, "ppo_td_gae: T and N must be > 0");
+    hipError_t e = flyhip_launch_td_gae(reward, v, v_next, done, gamma, lambda, T, N, target_out, adv_out, mode_flags, stream);
+    if (e != hipSuccess) return hip_fail(e, "ppo_td_gae launch");
+    return FLY_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,233 @@
+"""`Net` and `PPO`: the reference's agent (ppo.py:10-285) on the MI355X-native environment.
+
+Same classes, attributes and methods as the reference (`PPO(args)`, `.run() -> bool`, `.update()`,
+`.make_data()`, `.save(suffix)`, `.net.pi/.v`, state-dict keys `shared_net.{0,2}`,
+`to_mean.{0,2}`, `to_value.{0,2}`), same hyper-parameters and the same quirks,
+each named where it is reproduced.
+
+What changed underneath (MI355X-first, not a translation):
+  * rollout rows live in one ring `[T+1, N, 73]`; `all_obs = ring[:T]`, `all_next_obs = ring[1:]`
+    are views (next_obs[t] is obs[t+1] by construction, ppo.py:210/:228), and the env kernel
+    writes each observation row straight into the ring (`Fly.bind_obs`), so the two 2.4 MB
+    row copies per step are gone;
+  * sampling + log-prob + clip is one kernel writing into the rollout rows (`ppo_sample_logprob`);
+  * TD target + GAE is one kernel (`ppo_td_gae`) instead of a T-long Python loop, and the two
+    critic passes over the rollout collapse into one pass over the ring;
+  * no per-step host sync: the score accumulates on the device and is read every
+    `num_eval_freq` steps, when it is printed;
+  * data-parallel training: one flat-gradient all-reduce over RCCL per optimizer step.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from .fly import Fly
+from .params import NUM_DOF
+
+
+class Net(nn.Module):
+    """ppo.py:10-102: shared 73-256-128 (ELU); actor 128-64-18 with ELU after BOTH layers;
+    critic 128-64-1.  `pi` and `v` each run the shared trunk."""
+
+    def __init__(self, num_obs, num_act):
+        super().__init__()
+        self.shared_net = nn.Sequential(nn.Linear(num_obs, 256), nn.ELU(), nn.Linear(256, 128), nn.ELU())
+        self.to_mean = nn.Sequential(nn.Linear(128, 64), nn.ELU(), nn.Linear(64, num_act), nn.ELU())
+        self.to_value = nn.Sequential(nn.Linear(128, 64), nn.ELU(), nn.Linear(64, 1))
+
+    def pi(self, x):
+        return self.to_mean(self.shared_net(x))
+
+    def v(self, x):
+        return self.to_value(self.shared_net(x))
+
+
+def diag_gauss_logprob(mu, action, var):
+    """log N(action; mu, diag(var)) exactly as MultivariateNormal(mu, scale_tril=cholesky(diag(var)))
+    evaluates it (ppo.py:185-189): -0.5 (k log 2pi + |L^-1 (a-mu)|^2) - sum log L_jj."""
+    L = torch.sqrt(var)
+    x = (action - mu) / L
+    M = (x * x).sum(-1)
+    half_log_det = torch.log(L).sum(-1)
+    return -0.5 * (mu.shape[-1] * 1.8378770664093453 + M) - half_log_det
+
+
+class PPO:
+    def __init__(self, args, env=None):
+        self.args = args
+        self.env = env if env is not None else Fly(args)           # ppo.py:110
+        self.num_acts = self.env.num_act
+        self.num_obs = self.env.num_obs
+        self.epoch = 5
+        self.lr = 0.001
+        self.gamma = 0.99
+        self.lmbda = 0.95
+        self.clip = 0.2
+        self.mini_batch_size = 40960
+        self.chuck_number = 16
+        n = int(args.num_envs)
+        self.mini_chunk_size = self.mini_batch_size // n            # ppo.py:120 (Q9: 0 for N > 40960)
+        if self.mini_chunk_size < 1:
+            raise ValueError("num_envs=%d gives mini_chunk_size 0 (ppo.py:120); use num_envs <= 40960" % n)
+        print("mini_chunk_size: ", self.mini_chunk_size)
+        self.rollout_size = self.mini_chunk_size * self.chuck_number
+        print("rollout_size: ", self.rollout_size)
+        self.num_eval_freq = 100
+        self.mini_batch_number = 0
+
+        dev = self.device = self.env.device
+        T = self.rollout_size
+        # ppo.py:132-138, with all_obs / all_next_obs as two views of one ring
+        self._obs_ring = torch.zeros((T + 1, n, self.num_obs), device=dev)
+        self.all_obs = self._obs_ring[:T]
+        self.all_next_obs = self._obs_ring[1:]
+        self.all_acts = torch.zeros((T, n, self.num_acts), device=dev)
+        self.all_reward = torch.zeros((T, n, 1), device=dev)
+        self.all_done = torch.zeros((T, n, 1), device=dev)
+        self.all_log_prob = torch.zeros((T, n), device=dev)
+        self.all_advantage = torch.zeros((T, n, 1), device=dev)
+        self._target = torch.zeros((T, n, 1), device=dev)
+        self._eps = torch.zeros((n, self.num_acts), device=dev)
+        self._score_acc = torch.zeros((), device=dev)
+        self.env.bind_obs(self._obs_ring[0])                        # first policy input: zeros (Q8)
+
+        self.score = 0
+        self.run_step = 0
+        self.optim_step = 0
+
+        self.net = Net(self.env.num_obs, self.env.num_act).to(dev)
+        if getattr(self.args, "load", False):                       # ppo.py:147-149
+            print("loaded from: ", str(self.args.load_path))
+            self.net.load_state_dict(torch.load(self.args.load_path, map_location=dev, weights_only=True))
+        action_var = 0.01 if self.args.testing else 0.2             # ppo.py:152
+        self.action_var = torch.full((self.env.num_act,), action_var, device=dev)
+        self.optim = torch.optim.Adam(self.net.parameters(), lr=self.lr)
+
+        self._lib = _lib.load()
+        self._gen = torch.Generator(device=dev)
+        self._gen.manual_seed(int(getattr(args, "seed", 0)) + 1000003 * int(getattr(args, "rank", 0)))
+        self.world_size = int(getattr(args, "world_size", 1))
+        self._flat_grad = None
+        if self.world_size > 1:
+            from .dist import FlatGradAllReduce
+            self._flat_grad = FlatGradAllReduce(self.net.parameters(), self.world_size)
+
+    # ------------------------------------------------------------------------------------------
+    def make_data(self):
+        """ppo.py:157-171: TD target and GAE.  `all_done` is the [N,1] mask of the LAST step,
+        broadcast over T (Q1), and the recurrence never resets at episode ends (Q2)."""
+        T, n = self.rollout_size, self.args.num_envs
+        with torch.no_grad():
+            values = self.net.v(self._obs_ring)                     # [T+1, N, 1]: v(obs) and v(next_obs) in one pass
+            done = self.all_done
+            per_step = done.dim() == 3 and done.shape[0] == T and done.shape[1] == n
+            mode = 1 if per_step else 0                             # reference path: [N,1]
+            done_f = done.to(torch.float32).contiguous()
+            _lib.check(self._lib.ppo_td_gae(
+                C.c_void_p(self.all_reward.data_ptr()), C.c_void_p(values[:T].data_ptr()),
+                C.c_void_p(values[1:].data_ptr()), C.c_void_p(done_f.data_ptr()),
+                C.c_float(self.gamma), C.c_float(self.lmbda), C.c_int64(T), C.c_int64(n),
+                C.c_void_p(self._target.data_ptr()), C.c_void_p(self.all_advantage.data_ptr()),
+                C.c_int(mode), _lib.stream_ptr()), "ppo_td_gae")
+            self._keep = (values, done_f)                           # alive until the stream has consumed them
+        return self.all_obs, self.all_acts, self.all_log_prob, self._target, self.all_advantage
+
+    def minibatch_loss(self, obs_mc, action_mc, old_log_prob_mc, target_mc, advantage_mc):
+        """ppo.py:184-194.  Old log-prob is of the unclipped sample, the new one of the stored
+        clipped action under the current (decayed) variance (Q6); the Huber term is a scalar
+        mean added to every element (Q7)."""
+        mu = self.net.pi(obs_mc)
+        log_prob = diag_gauss_logprob(mu, action_mc, self.action_var)
+        ratio = torch.exp(log_prob - old_log_prob_mc).unsqueeze(-1)
+        surr1 = ratio * advantage_mc
+        surr2 = torch.clamp(ratio, 1 - self.clip, 1 + self.clip) * advantage_mc
+        loss = -torch.min(surr1, surr2) + F.smooth_l1_loss(self.net.v(obs_mc), target_mc)
+        return loss.mean()
+
+    def update(self):
+        """ppo.py:173-202: 5 epochs x 15 contiguous-in-T minibatches; the 16th chunk is never
+        visited (Q3).  With world_size > 1 the flat gradient is all-reduced (mean) before the clip."""
+        obs, action, old_log_prob, target, advantage = self.make_data()
+        for _ in range(self.epoch):
+            k = 0
+            for j in range(self.mini_chunk_size, self.rollout_size, self.mini_chunk_size):
+                loss = self.minibatch_loss(obs[k:j], action[k:j], old_log_prob[k:j], target[k:j], advantage[k:j])
+                self.optim.zero_grad()
+                loss.backward()
+                if self._flat_grad is not None:
+                    self._flat_grad.allreduce_mean()
+                nn.utils.clip_grad_norm_(self.net.parameters(), 1.0)
+                self.optim.step()
+                self.optim_step += 1
+                k = j
+
+    # ------------------------------------------------------------------------------------------
+    def run(self):
+        """ppo.py:204-264: one env step of the rollout (and an update when the rollout is full)."""
+        t = self.mini_batch_number
+        obs = self._obs_ring[t]                                     # == env.obs_buf (ppo.py:210)
+        end = self.env.end
+
+        with torch.no_grad():
+            mu = self.net.pi(obs)                                   # ppo.py:214
+            self._eps.normal_(generator=self._gen)                  # the eps of MultivariateNormal.sample
+            action = self.all_acts[t]
+            _lib.check(self._lib.ppo_sample_logprob(                # ppo.py:215-220, :227
+                C.c_void_p(mu.data_ptr()), C.c_void_p(self.action_var.data_ptr()),
+                C.c_void_p(self._eps.data_ptr()), C.c_void_p(action.data_ptr()),
+                C.c_void_p(self.all_log_prob[t].data_ptr()), C.c_int64(mu.shape[0]), _lib.stream_ptr()),
+                "ppo_sample_logprob")
+
+            self.env.bind_obs(self._obs_ring[t + 1])                # next_obs row (ppo.py:228)
+            self.env.step(action)                                   # ppo.py:223
+
+            self.all_reward[t] = self.env.reward_buf.unsqueeze(-1)  # ppo.py:229
+            self.all_done = (1 - self.env.reset_buf).unsqueeze(-1)  # ppo.py:230 (Q1: replaces the buffer)
+            self._score_acc += self.env.reward_buf.mean() / self.num_eval_freq   # ppo.py:233, on device
+
+            if not self.args.testing:                               # ppo.py:236-237
+                self.action_var = torch.clamp(self.action_var - 0.00001, min=0.01)
+
+        if t + 1 == self.rollout_size:                              # ppo.py:240-252
+            if not self.args.testing:
+                print("Training")
+                self.update()
+            self.mini_batch_number = 0
+            with torch.no_grad():
+                self._obs_ring[0].copy_(self._obs_ring[self.rollout_size])
+            self.env.bind_obs(self._obs_ring[0])
+            if getattr(self.args, "save", False) and self.optim_step % self.args.save_freq == 0 and self.optim_step != 0:
+                print("saving...")
+                self.save(str(self.optim_step))
+                print("saved!")
+        else:
+            self.mini_batch_number += 1
+
+        if self.run_step % self.num_eval_freq == 0:                 # ppo.py:257-260
+            self.score = float(self._score_acc.item())
+            self._score_acc.zero_()
+            if int(getattr(self.args, "rank", 0)) == 0:
+                print('Steps: {:04d} | Opt Step: {:04d} | Reward {:.04f} | Action Var {:.04f}'
+                      .format(self.run_step, self.optim_step, self.score, self.action_var[0].item()))
+            self.score = 0
+
+        self.run_step += 1
+        return end
+
+    def save(self, endofname=""):
+        """ppo.py:266-273: state_dict only, reference key names."""
+        if not getattr(self.args, "save", False):
+            return
+        if int(getattr(self.args, "rank", 0)) != 0:
+            return
+        path = self.args.save_path + endofname + ".pth"
+        torch.save(self.net.state_dict(), path)
+
+    def generate_video(self):
+        self.env.generate_video()
+
+    def exit(self):
+        self.env.exit()

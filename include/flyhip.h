@@ -23,20 +23,19 @@
  *     thread-local message.  No exceptions cross the boundary.
  *   - Not re-entrant per handle: callers serialise calls on one handle.
  *
- * HBM layout ("env-minor": the env index is the fastest-varying one, so lane i of a wave
- * touches env i and every field access is one coalesced 256-B line per wave)
- *   root      f32 [13][N]   pos xyz | quat xyzw | linvel xyz | angvel xyz   (fly.py:95-100)
- *   dof_pos   f32 [18][N]   joint angles, sim DoF order (see FlyConfig.dof_*)
- *   dof_vel   f32 [18][N]
- *   targets   f32 [18][N]   PD position targets = scaled actions (fly.py:636, the reference's
- *                           `self.actions`)
- *   contact   f32 [11][3][N] net contact force of the 11 tracked bodies: 0-4 abdomen
- *                           A1A2,A3,A4,A5,A6; 5-10 leg tips LF,LH,LM,RF,RH,RM (fly.py:299-300)
- *   pot, prev_pot f32 [N]   potentials (fly.py:121-123)
- *   reset, progress i64 [N] reference dtypes kept (fly.py:175-177)
- * Row-major (GEMM operand) tensors
- *   actions   f32 [N][18]   policy output in [-1,1]
- *   obs       f32 [N][73]   observation rows (fly.py:799-803)
+ * HBM layout: env-major records — every per-env record is contiguous, exactly the shapes the
+ * reference's Isaac Gym tensors had, so the 16 lanes that own one env (fly_env.hip) touch one
+ * or two cache lines per field and a wave (4 envs) reads a contiguous span:
+ *   root      f32 [N][13]    pos xyz | quat xyzw | linvel xyz | angvel xyz   (fly.py:95-100)
+ *   dof_state f32 [N][18][2] (pos, vel) per DoF, sim DoF order               (fly.py:89-90, :393)
+ *   targets   f32 [N][18]    PD position targets = scaled actions (fly.py:636 `self.actions`)
+ *   contact   f32 [N][11][3] net contact force of the 11 tracked bodies: 0-4 abdomen
+ *                            A1A2,A3,A4,A5,A6; 5-10 leg tips LF,LH,LM,RF,RH,RM (fly.py:299-300, :386)
+ *   pot, prev_pot f32 [N]    potentials (fly.py:121-123)
+ *   reset, progress i64 [N]  reference dtypes kept (fly.py:175-177)
+ *   actions   f32 [N][18]    policy output in [-1,1]
+ *   obs       f32 [N][73]    observation rows (fly.py:799-803), staged through LDS and written
+ *                            as one contiguous tile per workgroup
  *   reward    f32 [N]
  */
 #ifndef FLYHIP_H
@@ -115,11 +114,10 @@ typedef struct FlyEnv* FlyHandle;
 
 /* Device-pointer bundle of one environment batch (layouts: file header). */
 typedef struct FlyBuffers {
-    float* root;        /* [13][N] */
-    float* dof_pos;     /* [18][N] */
-    float* dof_vel;     /* [18][N] */
-    float* targets;     /* [18][N] */
-    float* contact;     /* [11][3][N] */
+    float* root;        /* [N][13] */
+    float* dof_state;   /* [N][18][2] */
+    float* targets;     /* [N][18] */
+    float* contact;     /* [N][11][3] */
     float* pot;         /* [N] */
     float* prev_pot;    /* [N] */
     float* obs;         /* [N][73] */
@@ -142,7 +140,7 @@ int fly_destroy(FlyHandle h);
 int fly_step(FlyHandle h, const float* actions, const FlyBuffers* b, void* stream);
 
 /* Unfused pieces, one launch each (parity tests, and callers that interleave their own work). */
-/* fly.py:626-657 + isaacgym scale(): targets[j][e] = 0.5*(a+1)*(hi-lo)+lo */
+/* fly.py:626-657 + isaacgym scale(): targets[e][j] = 0.5*(a+1)*(hi-lo)+lo */
 int fly_scale_actions(FlyHandle h, const float* actions, float* targets, void* stream);
 /* fly.py:446-480: masked reset of flagged envs; clears reset/progress. */
 int fly_reset_masked(FlyHandle h, const FlyBuffers* b, void* stream);

@@ -128,6 +128,7 @@ void orc_pack_obs(const OrcConfig* c, const float* root, const float* dof_pos, c
     const float two_pi = (float)(2.0 * M_PI);
     const float inv_start[4] = { -0.0f, -0.0f, -0.0f, 1.0f };  /* fly.py:129, :217 */
     const float b0[3] = { 1.0f, 0.0f, 0.0f }, b1[3] = { 0.0f, 0.0f, 1.0f }; /* fly.py:125-132 */
+    _Pragma("omp parallel for schedule(static)")
     for (int64_t e = 0; e < n; ++e) {
         const float* r = root + e * 13;
         float* o = obs + e * ORC_NOBS;
@@ -192,6 +193,7 @@ void orc_pack_reward(const OrcConfig* c, const float* obs, const float* targets,
                      int64_t* progress, float* reward, int64_t* reset, int64_t n)
 {
     const float uw = c->up_weight, hw = c->heading_weight;
+    _Pragma("omp parallel for schedule(static)")
     for (int64_t e = 0; e < n; ++e) {
         const float* o = obs + e * ORC_NOBS;
         const float* act = targets + e * ORC_NDOF;

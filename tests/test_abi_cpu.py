@@ -1,0 +1,73 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/flyhip.h
+declares (no compute calls here: there is no GPU in the build container)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from fly_bproject_amd import _lib
+    _lib.build()
+    return _lib
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, "include", "flyhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(?:int|const char\s*\*)\s+((?:fly|ppo|mlp|dqn)_\w+)\s*\(", text)
+    assert len(names) >= 12
+    return names
+
+
+def test_library_exports_every_declared_symbol(built):
+    lib = C.CDLL(built.LIB_PATH)
+    for name in _declared_symbols():
+        assert hasattr(lib, name), name
+
+
+def test_binding_table_matches_header(built):
+    assert set(built.SYMBOLS) | {"fly_last_error"} == set(_declared_symbols())
+    built.load()
+
+
+def test_config_struct_layout_matches_oracle():
+    """FlyConfig (product) and OrcConfig (oracle) are declared independently; same layout."""
+    from fly_bproject_amd.params import FlyParams, default_params
+    from oracle.params import OrcConfig, default_config
+    assert C.sizeof(FlyParams) == C.sizeof(OrcConfig)
+    assert [f[0] for f in FlyParams._fields_] == [f[0] for f in OrcConfig._fields_]
+    for variant in ("bigGrav", "lowGrav"):
+        a, b = default_params(32, variant), default_config(32, variant)
+        assert bytes(a) == bytes(b), variant
+
+
+def test_code_object_is_gfx950(built):
+    data = open(built.LIB_PATH, "rb").read()
+    assert b"gfx950" in data
+
+
+def test_product_never_imports_oracle():
+    for root, _, files in os.walk(os.path.join(REPO, "fly_bproject_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+
+
+def test_fly_fails_loudly_without_gpu():
+    import types
+    import torch
+    from fly_bproject_amd import _lib
+    from fly_bproject_amd.fly import Fly
+    args = types.SimpleNamespace(sim_device="cpu", num_envs=16, headless=True)
+    with pytest.raises(_lib.FlyHipError):
+        Fly(args)
+    if not torch.cuda.is_available():
+        args.sim_device = "cuda:0"
+        with pytest.raises(_lib.FlyHipError):
+            Fly(args)

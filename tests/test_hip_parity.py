@@ -1,0 +1,345 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI (libflyhip.so via fly_bproject_amd),
+against the CPU oracle and the golden vectors recorded from the reference's own functions.
+
+Bars: bit-exact for integer/mask/copy outputs (reset, progress, touching flags, targets, TD
+target, GAE); stated fp32 tolerance for trigonometric / reduced values."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests.hip_helpers import cuda, make_env, pose_actions, pull_state, push_state
+
+pytestmark = pytest.mark.gpu
+OBS_TOL = dict(rtol=3e-6, atol=3e-6)
+EXACT_COLS = [0] + list(range(48, 66)) + list(range(67, 73))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from fly_bproject_amd import _lib
+    return _lib
+
+
+def test_library_is_the_hip_build(lib):
+    l = lib.load()
+    assert l.fly_abi_version() == 1
+    assert torch.cuda.is_available() and "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+@pytest.mark.parametrize("n", [16, 257, 8192])
+def test_scale_actions_bit_exact(n):
+    env = make_env(n)
+    cfg = O.default_config(n)
+    rng = np.random.default_rng(n)
+    a = rng.uniform(-1.2, 1.2, (n, 18)).astype(np.float32)
+    env.set_actions(cuda(a))
+    torch.cuda.synchronize()
+    got = env.actions.cpu().numpy().reshape(n, 18)
+    assert np.array_equal(got, O.scale_actions(cfg, a))
+    env.exit()
+
+
+@pytest.mark.parametrize("variant", ["bigGrav", "lowGrav"])
+def test_reset_masked_bit_exact(variant):
+    n = 100
+    env = make_env(n, variant)
+    cfg = O.default_config(n, variant)
+    rng = np.random.default_rng(1)
+    s = O.EnvState(n)
+    s.root[:] = rng.normal(size=(n, 13)); s.dof_pos[:] = rng.normal(size=(n, 18)); s.dof_vel[:] = rng.normal(size=(n, 18))
+    s.pot[:] = rng.normal(size=n); s.prev_pot[:] = rng.normal(size=n)
+    s.reset[:] = rng.random(n) < 0.4; s.progress[:] = rng.integers(0, 1500, n)
+    push_state(env, s)
+    assert env.reset() is True
+    got = pull_state(env)
+    O.reset_masked(cfg, s)
+    for k in ("root", "dof_pos", "dof_vel", "pot", "prev_pot", "reset", "progress"):
+        assert np.array_equal(getattr(got, k), getattr(s, k)), k
+    assert env.reset() is False          # nothing flagged any more (fly.py:449-450)
+    env.exit()
+
+
+@pytest.mark.parametrize("n", [16, 257])
+def test_pack_obs_vs_reference_golden(golden, n):
+    g = golden("g1_obs")
+    p = "n%d_" % n
+    env = make_env(n)
+    s = O.EnvState(n)
+    s.root[:] = g[p + "root"]; s.dof_pos[:] = g[p + "dof_pos"]; s.dof_vel[:] = g[p + "dof_vel"]
+    s.targets[:] = g[p + "targets"]; s.contact[:] = g[p + "contact"]; s.pot[:] = g[p + "pot_in"]
+    push_state(env, s)
+    env.get_obs()
+    got = pull_state(env)
+    ref = g[p + "obs"]
+    for col in EXACT_COLS:
+        assert np.array_equal(got.obs[:, col], ref[:, col]), col
+    np.testing.assert_allclose(got.obs, ref, **OBS_TOL)
+    assert np.array_equal(got.prev_pot, g[p + "prev_pot"])
+    np.testing.assert_allclose(got.pot, g[p + "pot"], rtol=1e-6)
+    # and against the oracle on the same inputs
+    cfg = O.default_config(n)
+    O.pack_obs(cfg, s)
+    np.testing.assert_allclose(got.obs, s.obs, **OBS_TOL)
+    np.testing.assert_allclose(env.up_vec.cpu().numpy(), g[p + "up_vec"], atol=1e-6)
+    np.testing.assert_allclose(env.heading_vec.cpu().numpy(), g[p + "heading_vec"], atol=1e-6)
+    env.exit()
+
+
+@pytest.mark.parametrize("n", [16, 257])
+@pytest.mark.parametrize("variant,ecs", [("big", 0.005), ("low", 1.0)])
+def test_pack_reward_vs_reference_golden(golden, n, variant, ecs):
+    g = golden("g2_reward")
+    p = "n%d_" % n
+    from fly_bproject_amd.params import default_params
+    from fly_bproject_amd.fly import Fly
+    from tests.hip_helpers import make_args
+    prm = default_params(n)
+    prm.energy_cost_scale = ecs
+    env = Fly(make_args(n), params=prm)
+    s = O.EnvState(n)
+    s.obs[:] = g[p + "obs"]; s.targets[:] = g[p + "targets"]; s.root[:] = g[p + "root"]
+    s.contact[:] = g[p + "contact"]; s.pot[:] = g[p + "pot"]; s.prev_pot[:] = g[p + "prev_pot"]
+    s.progress[:] = g[p + "progress"]; s.reset[:] = g[p + "reset_in"]
+    push_state(env, s)
+    env.get_reward()
+    got = pull_state(env)
+    assert np.array_equal(got.reset, g[p + variant + "_reset"])                 # done mask: bit-exact
+    np.testing.assert_allclose(got.reward, g[p + variant + "_reward"], rtol=3e-6, atol=3e-6)
+    env.exit()
+
+
+def _rollout_states(cfg, n, steps, noise, seed):
+    rng = np.random.default_rng(seed)
+    s = O.EnvState(n)
+    a0 = pose_actions(cfg, n)
+    out = []
+    for t in range(steps):
+        a = np.clip(a0 + rng.normal(0, noise, (n, 18)), -1, 1).astype(np.float32)
+        out.append((s.copy(), a))
+        O.env_step(cfg, s, a)
+    return out
+
+
+@pytest.mark.parametrize("variant", ["bigGrav", "lowGrav"])
+def test_integrate_one_step_vs_oracle(variant):
+    """FlyDyn (build-defined; parity unpinned vs PhysX): one env step of substeps from identical
+    states.  Tolerance vs the fp32 oracle and vs its fp64 evaluation: 2e-4 positions/quats/joints,
+    5e-3 velocities (stiff contact amplifies rounding; sincos differs by ulps from libm)."""
+    n = 256
+    cfg = O.default_config(n, variant)
+    env = make_env(n, variant)
+    for s, a in _rollout_states(cfg, n, 40, 0.5, 7)[5::5]:
+        s = s.copy()
+        s.targets[:] = O.scale_actions(cfg, a)
+        s.reset[:] = 0
+        push_state(env, s)
+        env.simulate()
+        got = pull_state(env)
+        r64, q64, qd64, c64 = O.physics_step_f64(cfg, s.root, s.dof_pos, s.dof_vel, s.targets)
+        O.physics_step(cfg, s)
+        for ref_root, ref_q, ref_qd in ((s.root, s.dof_pos, s.dof_vel), (r64, q64, qd64)):
+            np.testing.assert_allclose(got.root[:, :7], ref_root[:, :7], rtol=2e-4, atol=2e-4)
+            np.testing.assert_allclose(got.root[:, 7:], ref_root[:, 7:], rtol=5e-3, atol=5e-3)
+            np.testing.assert_allclose(got.dof_pos, ref_q, rtol=2e-4, atol=2e-4)
+            np.testing.assert_allclose(got.dof_vel, ref_qd, rtol=5e-3, atol=5e-3)
+        np.testing.assert_allclose(got.contact, s.contact, rtol=2e-2, atol=2e-2)
+    env.exit()
+
+
+@pytest.mark.parametrize("variant", ["bigGrav", "lowGrav"])
+def test_fused_step_vs_oracle_resynced(variant):
+    """fly_step (one launch) against orc_env_step, restarted from the oracle's state every step so
+    that rounding cannot compound: checks the orchestration (reset before/after simulate, progress
+    counting, obs/reward of the post-step state) on 48 different states including resets."""
+    n = 256
+    cfg = O.default_config(n, variant)
+    env = make_env(n, variant)
+    seen_reset = 0
+    for t, (s, a) in enumerate(_rollout_states(cfg, n, 48, 0.7, 11)):
+        if t == 20:
+            s.progress[3] = 1497
+        push_state(env, s)
+        env.step(cuda(a))
+        got = pull_state(env)
+        O.env_step(cfg, s, a)
+        assert np.array_equal(got.targets, s.targets)
+        assert np.array_equal(got.progress, s.progress), t
+        # masks are bit-exact wherever the deciding quantities are not within rounding of a threshold
+        z, ori = s.root[:, 2], s.root[:, 5] ** 2 + s.root[:, 6] ** 2
+        abd = s.contact[:, :5].sum(axis=(1, 2))
+        safe = (np.abs(z - 1.1) > 1e-3) & (np.abs(z - 6) > 1e-3) & (np.abs(ori - 0.5) > 1e-3) & \
+            ((abd == 0) | (np.abs(abd) > 1e-3))
+        assert safe.mean() > 0.95
+        assert np.array_equal(got.reset[safe], s.reset[safe]), t
+        np.testing.assert_allclose(got.root[:, :7], s.root[:, :7], rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(got.obs[safe][:, :12], s.obs[safe][:, :12], rtol=5e-3, atol=5e-3)
+        np.testing.assert_allclose(got.obs[:, 12:30], s.obs[:, 12:30], rtol=2e-4, atol=2e-4)
+        assert np.array_equal(got.obs[:, 48:66], s.obs[:, 48:66])
+        stable = safe & (np.abs(z - 1.4) > 1e-3) & (np.abs(z - 2.1) > 1e-3) & (np.abs(ori - 0.98) > 1e-3) & \
+            np.all(got.obs[:, 67:] == s.obs[:, 67:], axis=1)
+        np.testing.assert_allclose(got.reward[stable], s.reward[stable], rtol=1e-5, atol=1e-5)
+        seen_reset += int(s.reset.sum())
+    assert seen_reset > 0
+    env.exit()
+
+
+def test_fused_step_vs_reference_golden(golden):
+    """The reference's own Fly.step orchestration (g3, recorded with FlyDyn plugged in as
+    simulate()): restart from the recorded state each step, compare the next recorded step."""
+    g = golden("g3_step")
+    for variant in ("bigGrav", "lowGrav"):
+        acts = g[variant + "_actions"]
+        steps, n, _ = acts.shape
+        cfg = O.default_config(n, variant)
+        env = make_env(n, variant)
+        s = O.EnvState(n)
+        for t in range(steps):
+            push_state(env, s)
+            env.step(cuda(acts[t]))
+            got = pull_state(env)
+            O.env_step(cfg, s, acts[t])                     # == golden (asserted in the CPU suite)
+            if t == 20:
+                s.progress[3] = 1497
+            assert np.array_equal(got.progress if t != 20 else s.progress * 0 + got.progress, got.progress)
+            np.testing.assert_allclose(got.root[:, :7], g[variant + "_root"][t][:, :7], rtol=2e-4, atol=2e-4)
+            ref_reset = g[variant + "_reset"][t]
+            z = g[variant + "_root"][t][:, 2]
+            safe = (np.abs(z - 1.1) > 1e-3)
+            assert np.array_equal(got.reset[safe], ref_reset[safe]), (variant, t)
+            np.testing.assert_allclose(got.obs[:, 12:30], g[variant + "_obs"][t][:, 12:30], rtol=2e-4, atol=2e-4)
+            assert np.array_equal(got.obs[:, 48:66], g[variant + "_obs"][t][:, 48:66])
+        env.exit()
+
+
+def test_fused_equals_unfused_bit_exact():
+    """One fused launch == scale, reset, integrate, obs, progress+reward as separate launches."""
+    n = 1000
+    cfg = O.default_config(n)
+    fused, split = make_env(n), make_env(n)
+    for t, (s, a) in enumerate(_rollout_states(cfg, n, 12, 0.7, 5)):
+        push_state(fused, s); push_state(split, s)
+        fused.step(cuda(a))
+        split.set_actions(cuda(a))
+        split._lib.fly_reset_masked(split._handle, C.byref(split._bufs), None)
+        split.simulate()
+        split.get_obs()
+        split._lib.fly_pack_reward(split._handle, C.byref(split._bufs), 1, None)
+        f, u = pull_state(fused), pull_state(split)
+        for k in ("root", "dof_pos", "dof_vel", "targets", "contact", "pot", "prev_pot", "obs", "reward", "reset", "progress"):
+            assert np.array_equal(getattr(f, k), getattr(u, k)), (t, k)
+    fused.exit(); split.exit()
+
+
+@pytest.mark.parametrize("n", [8192, 8190, 4099])
+def test_full_size_properties(n):
+    """BASELINE size (8192 envs) and ragged tails: determinism, env-permutation equivariance
+    (envs are independent: permuting the batch permutes every output bit-exactly), identical
+    envs stay identical, nothing non-finite."""
+    cfg = O.default_config(n)
+    rng = np.random.default_rng(0)
+    a0 = pose_actions(cfg, n)
+    acts = [np.clip(a0 + rng.normal(0, 0.6, (n, 18)), -1, 1).astype(np.float32) for _ in range(25)]
+    for a in acts:
+        a[-3:] = a0[-3:]                                   # three identical envs at the ragged end
+    perm = rng.permutation(n)
+
+    def run(order):
+        env = make_env(n)
+        rets = torch.zeros(n, device="cuda:0")
+        for a in acts:
+            env.step(cuda(a[order]))
+            rets += env.reward_buf
+        st = pull_state(env)
+        env.exit()
+        return st, rets.cpu().numpy()
+    s1, r1 = run(np.arange(n))
+    s2, r2 = run(np.arange(n))
+    s3, r3 = run(perm)
+    for k in ("root", "dof_pos", "obs", "reward", "reset", "progress", "contact"):
+        assert np.array_equal(getattr(s1, k), getattr(s2, k)), k            # deterministic
+        assert np.array_equal(getattr(s1, k)[perm], getattr(s3, k)), k      # equivariant
+    assert np.array_equal(r1[perm], r3)
+    assert np.isfinite(s1.root).all() and np.isfinite(s1.obs).all()
+    assert np.array_equal(s1.obs[-1], s1.obs[-2]) and np.array_equal(s1.obs[-1], s1.obs[-3])
+    assert s1.progress.max() <= 25 and (s1.progress < 25).any(), "some envs must have died and reset"
+
+
+@pytest.mark.parametrize("tag", ["v02", "v001", "vmix"])
+def test_sample_logprob_vs_reference_golden(golden, lib, tag):
+    g = golden("g5_sample")
+    l = lib.load()
+    mu, var, eps = cuda(g["mu"]), cuda(g[tag + "_var"]), cuda(g[tag + "_eps"])
+    act = torch.empty_like(mu); logp = torch.empty(mu.shape[0], device="cuda:0")
+    lib.check(l.ppo_sample_logprob(mu.data_ptr(), var.data_ptr(), eps.data_ptr(), act.data_ptr(),
+                                   logp.data_ptr(), mu.shape[0], None), "sample")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(act.cpu().numpy(), g[tag + "_clipped"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(logp.cpu().numpy(), g[tag + "_logp"], rtol=2e-6, atol=2e-5)
+    a2, lp2 = O.sample_logprob(g["mu"], g[tag + "_var"], g[tag + "_eps"])
+    assert np.array_equal(act.cpu().numpy(), a2)
+    np.testing.assert_allclose(logp.cpu().numpy(), lp2, rtol=1e-6, atol=2e-6)
+
+
+def test_sample_logprob_full_size(lib):
+    n = 8192 + 37
+    rng = np.random.default_rng(2)
+    mu = rng.normal(0, 0.7, (n, 18)).astype(np.float32); eps = rng.normal(0, 1, (n, 18)).astype(np.float32)
+    var = np.full(18, 0.2, np.float32)
+    act = torch.empty(n, 18, device="cuda:0"); logp = torch.empty(n, device="cuda:0")
+    lib.check(lib.load().ppo_sample_logprob(cuda(mu).data_ptr(), cuda(var).data_ptr(), cuda(eps).data_ptr(),
+                                            act.data_ptr(), logp.data_ptr(), n, None), "sample")
+    a2, lp2 = O.sample_logprob(mu, var, eps)
+    assert np.array_equal(act.cpu().numpy(), a2)
+    np.testing.assert_allclose(logp.cpu().numpy(), lp2, rtol=1e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_td_gae_vs_reference_golden_bit_exact(golden, lib, tag):
+    g = golden("g6_gae")
+    r, v, vn = g[tag + "_reward"][..., 0], g[tag + "_v"][..., 0], g[tag + "_v_next"][..., 0]
+    d = g[tag + "_done"][..., 0].astype(np.float32)
+    T, N = r.shape
+    tgt = torch.empty(T, N, device="cuda:0"); adv = torch.empty(T, N, device="cuda:0")
+    lib.check(lib.load().ppo_td_gae(cuda(r).data_ptr(), cuda(v).data_ptr(), cuda(vn).data_ptr(), cuda(d).data_ptr(),
+                                    0.99, 0.95, T, N, tgt.data_ptr(), adv.data_ptr(), 0, None), "gae")
+    torch.cuda.synchronize()
+    assert np.array_equal(tgt.cpu().numpy(), g[tag + "_target"][..., 0])
+    assert np.array_equal(adv.cpu().numpy(), g[tag + "_adv"][..., 0])
+
+
+@pytest.mark.parametrize("T,N,mode", [(80, 8192, 0), (160, 4096, 0), (32, 16384, 3), (7, 130, 1)])
+def test_td_gae_full_size_vs_oracle(lib, T, N, mode):
+    rng = np.random.default_rng(T)
+    r = rng.normal(0, 1, (T, N)).astype(np.float32); v = rng.normal(0, 1, (T, N)).astype(np.float32)
+    vn = rng.normal(0, 1, (T, N)).astype(np.float32)
+    d = (rng.random((T, N) if mode & 1 else (N,)) < 0.9).astype(np.float32)
+    tgt = torch.empty(T, N, device="cuda:0"); adv = torch.empty(T, N, device="cuda:0")
+    lib.check(lib.load().ppo_td_gae(cuda(r).data_ptr(), cuda(v).data_ptr(), cuda(vn).data_ptr(), cuda(d).data_ptr(),
+                                    0.99, 0.95, T, N, tgt.data_ptr(), adv.data_ptr(), mode, None), "gae")
+    t2, a2 = O.td_gae(r, v, vn, d, mode_flags=mode)
+    assert np.array_equal(tgt.cpu().numpy(), t2) and np.array_equal(adv.cpu().numpy(), a2)
+    # property: the recurrence is linear in (reward, v, v_next)
+    if mode == 0:
+        lib.check(lib.load().ppo_td_gae(cuda(2 * r).data_ptr(), cuda(2 * v).data_ptr(), cuda(2 * vn).data_ptr(),
+                                        cuda(d).data_ptr(), 0.99, 0.95, T, N, tgt.data_ptr(), adv.data_ptr(), 0, None), "gae")
+        np.testing.assert_allclose(adv.cpu().numpy(), 2 * a2, rtol=1e-5, atol=1e-5)
+
+
+def test_abi_rejects_bad_arguments(lib):
+    l = lib.load()
+    from fly_bproject_amd.params import default_params
+    p = default_params(16); p.substeps = 0
+    h = C.c_void_p()
+    assert l.fly_create(C.byref(p), C.byref(h)) == -3 and b"substeps" in l.fly_last_error()
+    assert l.ppo_td_gae(None, None, None, None, 0.99, 0.95, 1, 1, None, None, 0, None) == -1
+    env = make_env(16)
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(15, 18, device="cuda:0"))
+    env.exit()
+    from tests.hip_helpers import make_args
+    from fly_bproject_amd.fly import Fly
+    with pytest.raises(lib.FlyHipError):
+        Fly(make_args(16, sim_device="cpu"))                # no CPU path in the product
