@@ -62,12 +62,18 @@ __device__ __forceinline__ float row_get(float x, int src)
     return __shfl(x, src, LANES_PER_ENV);
 }
 
+__device__ __forceinline__ float dot3(float a0, float a1, float a2, float b0, float b1, float b2)
+{
+    return fmaf(a0, b0, fmaf(a1, b1, a2 * b2));
+}
+__device__ __forceinline__ float clampf(float x, float lim) { return fminf(fmaxf(x, -lim), lim); }
+
 struct Root {
     float px, py, pz, qx, qy, qz, qw, vx, vy, vz, wx, wy, wz;
 };
 
-// ---- K4 helpers: separately rounded fp32, the op order of the published helper formulas ------
-#pragma clang fp contract(off)
+// ---- K4 helpers: separately rounded fp32 (the file is built with -ffp-contract=off; every fused
+// multiply-add in the physics is an explicit fmaf, so all template instances round identically) --
 __device__ __forceinline__ void quat_rot(const float q[4], float v0, float v1, float v2, float sign, float o[3])
 {
     float qw = q[3];
@@ -152,7 +158,6 @@ __device__ __forceinline__ float scale_action(float a, float lo, float hi)
     t = t * (hi - lo);
     return t + lo;
 }
-#pragma clang fp contract(fast)
 
 template <int PH>
 __global__ __launch_bounds__(BLOCK) void fly_kernel(const FlyConfig* __restrict__ c,
@@ -249,8 +254,10 @@ __global__ __launch_bounds__(BLOCK) void fly_kernel(const FlyConfig* __restrict_
         const int nsub = c->substeps;
         const float h = c->dt / (float)nsub;
         const float kp = c->kp, kd = c->kd, eff = c->effort, vmax = c->vmax, Jinv = 1.0f / c->joint_inertia;
-        const float m = c->mass, g = c->gravity;
+        const float minv = 1.0f / c->mass, g = c->gravity;
         const float I0 = c->inertia[0], I1 = c->inertia[1], I2 = c->inertia[2];
+        const float I0inv = 1.0f / I0, I1inv = 1.0f / I1, I2inv = 1.0f / I2;
+        const float vlim = c->max_lin_vel, wlim = c->max_ang_vel;
         const float kc = c->kc, cd = c->cdamp, mu = c->mu, cv = c->cvisc;
         const float Lf = c->femur_len, Lt = c->tibia_len;
         const float ld = 1.0f - h * c->lin_damp, ad = 1.0f - h * c->ang_damp;
@@ -264,22 +271,22 @@ __global__ __launch_bounds__(BLOCK) void fly_kernel(const FlyConfig* __restrict_
             // 1. joints (leg lanes; the others integrate zeros)
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                float tau = kp * (jt[i] - jq[i]) - kd * jqd[i];
+                float tau = fmaf(kp, jt[i] - jq[i], -(kd * jqd[i]));
                 tau = fminf(fmaxf(tau, -eff), eff);
-                float v = jqd[i] + h * tau * Jinv;
+                float v = fmaf(h * Jinv, tau, jqd[i]);
                 v = fminf(fmaxf(v, -vmax), vmax);
-                float x = jq[i] + h * v;
+                float x = fmaf(h, v, jq[i]);
                 if (x < lo[i]) { x = lo[i]; v = fmaxf(v, 0.0f); }
                 if (x > hi[i]) { x = hi[i]; v = fminf(v, 0.0f); }
                 jq[i] = x; jqd[i] = v;
             }
             // rotation matrix
             const float qx = r.qx, qy = r.qy, qz = r.qz, qw = r.qw;
-            const float R00 = 1 - 2 * (qy * qy + qz * qz), R01 = 2 * (qx * qy - qz * qw), R02 = 2 * (qx * qz + qy * qw);
-            const float R10 = 2 * (qx * qy + qz * qw), R11 = 1 - 2 * (qx * qx + qz * qz), R12 = 2 * (qy * qz - qx * qw);
-            const float R20 = 2 * (qx * qz - qy * qw), R21 = 2 * (qy * qz + qx * qw), R22 = 1 - 2 * (qx * qx + qy * qy);
+            const float R00 = fmaf(-2.0f, fmaf(qy, qy, qz * qz), 1.0f), R01 = 2.0f * fmaf(qx, qy, -(qz * qw)), R02 = 2.0f * fmaf(qx, qz, qy * qw);
+            const float R10 = 2.0f * fmaf(qx, qy, qz * qw), R11 = fmaf(-2.0f, fmaf(qx, qx, qz * qz), 1.0f), R12 = 2.0f * fmaf(qy, qz, -(qx * qw));
+            const float R20 = 2.0f * fmaf(qx, qz, -(qy * qw)), R21 = 2.0f * fmaf(qy, qz, qx * qw), R22 = fmaf(-2.0f, fmaf(qx, qx, qy * qy), 1.0f);
             // 2. this lane's contact point: leg kinematics, or a fixed abdomen point
-            float psi = azim + sg * (jq[0] - pose[0]);
+            float psi = fmaf(sg, jq[0] - pose[0], azim);
             float al = al0 + (jq[1] - pose[1]);
             float gm = al + be0 + (jq[2] - pose[2]);
             float psid = sg * jqd[0], ald = jqd[1], gmd = ald + jqd[2];
@@ -287,24 +294,24 @@ __global__ __launch_bounds__(BLOCK) void fly_kernel(const FlyConfig* __restrict_
             sincosf(psi, &sp, &cp);
             sincosf(al, &sa, &ca);
             sincosf(gm, &sgm, &cg);
-            float rho = Lf * ca + Lt * cg, zeta = Lf * sa + Lt * sgm;
-            float rhod = -Lf * sa * ald - Lt * sgm * gmd;
-            float zetad = Lf * ca * ald + Lt * cg * gmd;
-            float rbx = is_leg ? att0 + cp * rho : ab0;
-            float rby = is_leg ? att1 + sp * rho : ab1;
+            float rho = fmaf(Lf, ca, Lt * cg), zeta = fmaf(Lf, sa, Lt * sgm);
+            float rhod = -fmaf(Lf * sa, ald, Lt * sgm * gmd);
+            float zetad = fmaf(Lf * ca, ald, Lt * cg * gmd);
+            float rbx = is_leg ? fmaf(cp, rho, att0) : ab0;
+            float rby = is_leg ? fmaf(sp, rho, att1) : ab1;
             float rbz = is_leg ? att2 + zeta : ab2;
-            float rdx = is_leg ? (-sp * rho * psid + cp * rhod) : 0.0f;
-            float rdy = is_leg ? (cp * rho * psid + sp * rhod) : 0.0f;
+            float rdx = is_leg ? fmaf(cp, rhod, -(sp * rho * psid)) : 0.0f;
+            float rdy = is_leg ? fmaf(sp, rhod, cp * rho * psid) : 0.0f;
             float rdz = is_leg ? zetad : 0.0f;
-            float rwx = R00 * rbx + R01 * rby + R02 * rbz;
-            float rwy = R10 * rbx + R11 * rby + R12 * rbz;
-            float rwz = R20 * rbx + R21 * rby + R22 * rbz;
+            float rwx = dot3(R00, R01, R02, rbx, rby, rbz);
+            float rwy = dot3(R10, R11, R12, rbx, rby, rbz);
+            float rwz = dot3(R20, R21, R22, rbx, rby, rbz);
             float d = -(r.pz + rwz);
-            float ux = r.vx + (r.wy * rwz - r.wz * rwy) + (R00 * rdx + R01 * rdy + R02 * rdz);
-            float uy = r.vy + (r.wz * rwx - r.wx * rwz) + (R10 * rdx + R11 * rdy + R12 * rdz);
-            float uz = r.vz + (r.wx * rwy - r.wy * rwx) + (R20 * rdx + R21 * rdy + R22 * rdz);
-            float fn = fmaxf(kc * d * (1.0f - cd * uz), 0.0f);
-            float ut = sqrtf(ux * ux + uy * uy);
+            float ux = r.vx + fmaf(r.wy, rwz, -(r.wz * rwy)) + dot3(R00, R01, R02, rdx, rdy, rdz);
+            float uy = r.vy + fmaf(r.wz, rwx, -(r.wx * rwz)) + dot3(R10, R11, R12, rdx, rdy, rdz);
+            float uz = r.vz + fmaf(r.wx, rwy, -(r.wy * rwx)) + dot3(R20, R21, R22, rdx, rdy, rdz);
+            float fn = fmaxf(kc * d * fmaf(-cd, uz, 1.0f), 0.0f);
+            float ut = sqrtf(fmaf(ux, ux, uy * uy));
             float ft = fminf(cv * ut, mu * fn);
             float sc = ft / (ut + 1e-9f);
             const bool touch = contact_lane && (d > 0.0f);
@@ -313,33 +320,35 @@ __global__ __launch_bounds__(BLOCK) void fly_kernel(const FlyConfig* __restrict_
             float fz = touch ? fn : 0.0f;
             cf[0] = fx; cf[1] = fy; cf[2] = fz;
             float Fx = row_sum(fx), Fy = row_sum(fy), Fz = row_sum(fz);
-            float Tx = row_sum(rwy * fz - rwz * fy);
-            float Ty = row_sum(rwz * fx - rwx * fz);
-            float Tz = row_sum(rwx * fy - rwy * fx);
+            float Tx = row_sum(fmaf(rwy, fz, -(rwz * fy)));
+            float Ty = row_sum(fmaf(rwz, fx, -(rwx * fz)));
+            float Tz = row_sum(fmaf(rwx, fy, -(rwy * fx)));
             // 3. root, semi-implicit Euler (replicated over the row)
-            r.vx = (r.vx + h * (Fx / m)) * ld;
-            r.vy = (r.vy + h * (Fy / m)) * ld;
-            r.vz = (r.vz + h * (Fz / m + g)) * ld;
-            float wbx = R00 * r.wx + R10 * r.wy + R20 * r.wz;
-            float wby = R01 * r.wx + R11 * r.wy + R21 * r.wz;
-            float wbz = R02 * r.wx + R12 * r.wy + R22 * r.wz;
-            float tbx = R00 * Tx + R10 * Ty + R20 * Tz;
-            float tby = R01 * Tx + R11 * Ty + R21 * Tz;
-            float tbz = R02 * Tx + R12 * Ty + R22 * Tz;
-            float ax = (tbx - (wby * I2 * wbz - wbz * I1 * wby)) / I0;
-            float ay = (tby - (wbz * I0 * wbx - wbx * I2 * wbz)) / I1;
-            float az = (tbz - (wbx * I1 * wby - wby * I0 * wbx)) / I2;
-            wbx = (wbx + h * ax) * ad; wby = (wby + h * ay) * ad; wbz = (wbz + h * az) * ad;
-            r.wx = R00 * wbx + R01 * wby + R02 * wbz;
-            r.wy = R10 * wbx + R11 * wby + R12 * wbz;
-            r.wz = R20 * wbx + R21 * wby + R22 * wbz;
-            r.px += h * r.vx; r.py += h * r.vy; r.pz += h * r.vz;
+            r.vx = clampf(fmaf(h, Fx * minv, r.vx) * ld, vlim);
+            r.vy = clampf(fmaf(h, Fy * minv, r.vy) * ld, vlim);
+            r.vz = clampf(fmaf(h, fmaf(Fz, minv, g), r.vz) * ld, vlim);
+            float wbx = dot3(R00, R10, R20, r.wx, r.wy, r.wz);
+            float wby = dot3(R01, R11, R21, r.wx, r.wy, r.wz);
+            float wbz = dot3(R02, R12, R22, r.wx, r.wy, r.wz);
+            float tbx = dot3(R00, R10, R20, Tx, Ty, Tz);
+            float tby = dot3(R01, R11, R21, Tx, Ty, Tz);
+            float tbz = dot3(R02, R12, R22, Tx, Ty, Tz);
+            float ax = (tbx - fmaf(wby * I2, wbz, -(wbz * I1 * wby))) * I0inv;
+            float ay = (tby - fmaf(wbz * I0, wbx, -(wbx * I2 * wbz))) * I1inv;
+            float az = (tbz - fmaf(wbx * I1, wby, -(wby * I0 * wbx))) * I2inv;
+            wbx = clampf(fmaf(h, ax, wbx) * ad, wlim);
+            wby = clampf(fmaf(h, ay, wby) * ad, wlim);
+            wbz = clampf(fmaf(h, az, wbz) * ad, wlim);
+            r.wx = dot3(R00, R01, R02, wbx, wby, wbz);
+            r.wy = dot3(R10, R11, R12, wbx, wby, wbz);
+            r.wz = dot3(R20, R21, R22, wbx, wby, wbz);
+            r.px = fmaf(h, r.vx, r.px); r.py = fmaf(h, r.vy, r.py); r.pz = fmaf(h, r.vz, r.pz);
             const float hh = 0.5f * h;
-            float nqx = qx + hh * (r.wx * qw + r.wy * qz - r.wz * qy);
-            float nqy = qy + hh * (-r.wx * qz + r.wy * qw + r.wz * qx);
-            float nqz = qz + hh * (r.wx * qy - r.wy * qx + r.wz * qw);
-            float nqw = qw + hh * (-r.wx * qx - r.wy * qy - r.wz * qz);
-            float inv = 1.0f / sqrtf(nqx * nqx + nqy * nqy + nqz * nqz + nqw * nqw);
+            float nqx = fmaf(hh, fmaf(r.wx, qw, fmaf(r.wy, qz, -(r.wz * qy))), qx);
+            float nqy = fmaf(hh, fmaf(-r.wx, qz, fmaf(r.wy, qw, r.wz * qx)), qy);
+            float nqz = fmaf(hh, fmaf(r.wx, qy, fmaf(-r.wy, qx, r.wz * qw)), qz);
+            float nqw = fmaf(hh, -fmaf(r.wx, qx, fmaf(r.wy, qy, r.wz * qz)), qw);
+            float inv = 1.0f / sqrtf(fmaf(nqx, nqx, fmaf(nqy, nqy, fmaf(nqz, nqz, nqw * nqw))));
             r.qx = nqx * inv; r.qy = nqy * inv; r.qz = nqz * inv; r.qw = nqw * inv;
         }
     }

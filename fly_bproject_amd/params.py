@@ -65,6 +65,7 @@ class FlyParams(C.Structure):
         ("joint_inertia", C.c_float), ("mass", C.c_float), ("inertia", C.c_float * 3),
         ("kc", C.c_float), ("cdamp", C.c_float), ("mu", C.c_float), ("cvisc", C.c_float),
         ("lin_damp", C.c_float), ("ang_damp", C.c_float),
+        ("max_lin_vel", C.c_float), ("max_ang_vel", C.c_float),
         ("femur_len", C.c_float), ("tibia_len", C.c_float), ("alpha0", C.c_float), ("beta0", C.c_float),
         ("dof_lo", C.c_float * NUM_DOF), ("dof_hi", C.c_float * NUM_DOF), ("dof_pose", C.c_float * NUM_DOF),
         ("leg_attach", (C.c_float * 3) * NUM_LEGS), ("leg_azimuth", C.c_float * NUM_LEGS),
@@ -100,6 +101,7 @@ def default_params(num_envs, variant="bigGrav", reward="standing"):
     p.joint_inertia, p.mass = 1e-3, 1e-3
     p.inertia[:] = (6e-4, 8e-4, 1e-3)
     p.cdamp, p.lin_damp, p.ang_damp = 0.05, 0.5, 2.0
+    p.max_lin_vel, p.max_ang_vel = 1000.0, 64.0      # Isaac Gym AssetOptions defaults (fly.py:195)
     p.femur_len, p.tibia_len, p.alpha0, p.beta0 = 1.1, 1.2, -0.6, -1.1
     for j, name in enumerate(DOF_NAMES):
         p.dof_lo[j], p.dof_hi[j] = _limits(name)

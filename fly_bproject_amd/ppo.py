@@ -155,7 +155,10 @@ class PPO:
             k = 0
             for j in range(self.mini_chunk_size, self.rollout_size, self.mini_chunk_size):
                 loss = self.minibatch_loss(obs[k:j], action[k:j], old_log_prob[k:j], target[k:j], advantage[k:j])
-                self.optim.zero_grad()
+                if self._flat_grad is not None:
+                    self._flat_grad.zero()                          # grads are views of the flat buffer
+                else:
+                    self.optim.zero_grad()
                 loss.backward()
                 if self._flat_grad is not None:
                     self._flat_grad.allreduce_mean()

@@ -87,6 +87,7 @@ typedef struct FlyConfig {
     /* contact model, build-defined; mu = fly.py:39-40 */
     float kc, cdamp, mu, cvisc;
     float lin_damp, ang_damp;
+    float max_lin_vel, max_ang_vel;   /* per-component velocity clamps (Isaac Gym AssetOptions defaults 1000 / 64, fly.py:195) */
     /* leg kinematics, build-defined */
     float femur_len, tibia_len, alpha0, beta0;
     float dof_lo[FLY_NUM_DOF];   /* URDF joint limits, sim DoF order */

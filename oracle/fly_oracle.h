@@ -42,6 +42,7 @@ typedef struct OrcConfig {
     float inertia[3];
     float kc, cdamp, mu, cvisc;
     float lin_damp, ang_damp;
+    float max_lin_vel, max_ang_vel;   /* per-component velocity clamps (Isaac Gym AssetOptions defaults 1000 / 64, fly.py:195) */
     float femur_len, tibia_len, alpha0, beta0;
     float dof_lo[ORC_NDOF];
     float dof_hi[ORC_NDOF];

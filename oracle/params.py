@@ -53,6 +53,7 @@ class OrcConfig(C.Structure):
         ("joint_inertia", C.c_float), ("mass", C.c_float), ("inertia", C.c_float * 3),
         ("kc", C.c_float), ("cdamp", C.c_float), ("mu", C.c_float), ("cvisc", C.c_float),
         ("lin_damp", C.c_float), ("ang_damp", C.c_float),
+        ("max_lin_vel", C.c_float), ("max_ang_vel", C.c_float),
         ("femur_len", C.c_float), ("tibia_len", C.c_float), ("alpha0", C.c_float), ("beta0", C.c_float),
         ("dof_lo", C.c_float * NDOF), ("dof_hi", C.c_float * NDOF), ("dof_pose", C.c_float * NDOF),
         ("leg_attach", (C.c_float * 3) * NLEG), ("leg_azimuth", C.c_float * NLEG),
@@ -87,6 +88,7 @@ def default_config(num_envs, variant="bigGrav"):
     c.mass = 1e-3
     c.inertia[:] = [6e-4, 8e-4, 1e-3]
     c.cdamp = 0.05
+    c.max_lin_vel, c.max_ang_vel = 1000.0, 64.0
     c.lin_damp, c.ang_damp = 0.5, 2.0
     c.femur_len, c.tibia_len, c.alpha0, c.beta0 = 1.1, 1.2, -0.6, -1.1
     c.dof_lo[:] = DOF_LOWER
