@@ -161,6 +161,9 @@ def test_fused_step_vs_oracle_resynced(variant):
     for t, (s, a) in enumerate(_rollout_states(cfg, n, 48, 0.7, 11)):
         if t == 20:
             s.progress[3] = 1497
+        if t in (7, 30):
+            s.reset[5:9] = 1                                # flagged from outside (the viewer's R key, fly.py:498-500)
+        seen_reset += int(s.reset.sum())
         push_state(env, s)
         env.step(cuda(a))
         got = pull_state(env)
@@ -248,6 +251,7 @@ def test_full_size_properties(n):
     acts = [np.clip(a0 + rng.normal(0, 0.6, (n, 18)), -1, 1).astype(np.float32) for _ in range(25)]
     for a in acts:
         a[-3:] = a0[-3:]                                   # three identical envs at the ragged end
+        a[:8] = 1.0                                        # every joint to its upper limit: these fall over
     perm = rng.permutation(n)
 
     def run(order):
@@ -259,6 +263,7 @@ def test_full_size_properties(n):
         st = pull_state(env)
         env.exit()
         return st, rets.cpu().numpy()
+    acts = acts + acts                                     # 50 steps: long enough for the fallers to die
     s1, r1 = run(np.arange(n))
     s2, r2 = run(np.arange(n))
     s3, r3 = run(perm)
@@ -268,7 +273,7 @@ def test_full_size_properties(n):
     assert np.array_equal(r1[perm], r3)
     assert np.isfinite(s1.root).all() and np.isfinite(s1.obs).all()
     assert np.array_equal(s1.obs[-1], s1.obs[-2]) and np.array_equal(s1.obs[-1], s1.obs[-3])
-    assert s1.progress.max() <= 25 and (s1.progress < 25).any(), "some envs must have died and reset"
+    assert s1.progress.max() <= 50 and (s1.progress < 50).any(), "some envs must have died and reset"
 
 
 @pytest.mark.parametrize("tag", ["v02", "v001", "vmix"])
@@ -293,8 +298,10 @@ def test_sample_logprob_full_size(lib):
     mu = rng.normal(0, 0.7, (n, 18)).astype(np.float32); eps = rng.normal(0, 1, (n, 18)).astype(np.float32)
     var = np.full(18, 0.2, np.float32)
     act = torch.empty(n, 18, device="cuda:0"); logp = torch.empty(n, device="cuda:0")
-    lib.check(lib.load().ppo_sample_logprob(cuda(mu).data_ptr(), cuda(var).data_ptr(), cuda(eps).data_ptr(),
+    dmu, dvar, deps = cuda(mu), cuda(var), cuda(eps)
+    lib.check(lib.load().ppo_sample_logprob(dmu.data_ptr(), dvar.data_ptr(), deps.data_ptr(),
                                             act.data_ptr(), logp.data_ptr(), n, None), "sample")
+    torch.cuda.synchronize()
     a2, lp2 = O.sample_logprob(mu, var, eps)
     assert np.array_equal(act.cpu().numpy(), a2)
     np.testing.assert_allclose(logp.cpu().numpy(), lp2, rtol=1e-6, atol=2e-6)
@@ -307,7 +314,8 @@ def test_td_gae_vs_reference_golden_bit_exact(golden, lib, tag):
     d = g[tag + "_done"][..., 0].astype(np.float32)
     T, N = r.shape
     tgt = torch.empty(T, N, device="cuda:0"); adv = torch.empty(T, N, device="cuda:0")
-    lib.check(lib.load().ppo_td_gae(cuda(r).data_ptr(), cuda(v).data_ptr(), cuda(vn).data_ptr(), cuda(d).data_ptr(),
+    dr, dv, dvn, dd = cuda(r), cuda(v), cuda(vn), cuda(d)      # keep the device copies alive
+    lib.check(lib.load().ppo_td_gae(dr.data_ptr(), dv.data_ptr(), dvn.data_ptr(), dd.data_ptr(),
                                     0.99, 0.95, T, N, tgt.data_ptr(), adv.data_ptr(), 0, None), "gae")
     torch.cuda.synchronize()
     assert np.array_equal(tgt.cpu().numpy(), g[tag + "_target"][..., 0])
@@ -321,14 +329,18 @@ def test_td_gae_full_size_vs_oracle(lib, T, N, mode):
     vn = rng.normal(0, 1, (T, N)).astype(np.float32)
     d = (rng.random((T, N) if mode & 1 else (N,)) < 0.9).astype(np.float32)
     tgt = torch.empty(T, N, device="cuda:0"); adv = torch.empty(T, N, device="cuda:0")
-    lib.check(lib.load().ppo_td_gae(cuda(r).data_ptr(), cuda(v).data_ptr(), cuda(vn).data_ptr(), cuda(d).data_ptr(),
+    dr, dv, dvn, dd = cuda(r), cuda(v), cuda(vn), cuda(d)
+    lib.check(lib.load().ppo_td_gae(dr.data_ptr(), dv.data_ptr(), dvn.data_ptr(), dd.data_ptr(),
                                     0.99, 0.95, T, N, tgt.data_ptr(), adv.data_ptr(), mode, None), "gae")
+    torch.cuda.synchronize()
     t2, a2 = O.td_gae(r, v, vn, d, mode_flags=mode)
     assert np.array_equal(tgt.cpu().numpy(), t2) and np.array_equal(adv.cpu().numpy(), a2)
     # property: the recurrence is linear in (reward, v, v_next)
     if mode == 0:
-        lib.check(lib.load().ppo_td_gae(cuda(2 * r).data_ptr(), cuda(2 * v).data_ptr(), cuda(2 * vn).data_ptr(),
-                                        cuda(d).data_ptr(), 0.99, 0.95, T, N, tgt.data_ptr(), adv.data_ptr(), 0, None), "gae")
+        dr2, dv2, dvn2 = cuda(2 * r), cuda(2 * v), cuda(2 * vn)
+        lib.check(lib.load().ppo_td_gae(dr2.data_ptr(), dv2.data_ptr(), dvn2.data_ptr(),
+                                        dd.data_ptr(), 0.99, 0.95, T, N, tgt.data_ptr(), adv.data_ptr(), 0, None), "gae")
+        torch.cuda.synchronize()
         np.testing.assert_allclose(adv.cpu().numpy(), 2 * a2, rtol=1e-5, atol=1e-5)
 
 

@@ -1,0 +1,63 @@
+"""GPU (-m gpu): the PPO loop end to end on the native env — shapes of log.txt (75 optimizer
+steps per update), finiteness over several iterations, checkpoint wire format."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from tests.hip_helpers import make_args
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(agent, steps):
+    with contextlib.redirect_stdout(io.StringIO()):
+        for _ in range(steps):
+            agent.run()
+
+
+def test_two_iterations_stay_finite(tmp_path):
+    from fly_bproject_amd.ppo import PPO
+    torch.manual_seed(0)
+    args = make_args(4096, save=True, save_path=str(tmp_path / "ck_"), save_freq=75)
+    with contextlib.redirect_stdout(io.StringIO()):
+        agent = PPO(args)
+    assert agent.mini_chunk_size == 10 and agent.rollout_size == 160      # ppo.py:120-122
+    for it in range(2):
+        _run(agent, agent.rollout_size)
+        torch.cuda.synchronize()
+        assert agent.optim_step == 75 * (it + 1)                          # log.txt:48-49
+        assert torch.isfinite(agent._obs_ring).all(), "non-finite observation in the rollout"
+        assert torch.isfinite(agent.all_reward).all() and torch.isfinite(agent.all_advantage).all()
+        assert torch.isfinite(agent.all_log_prob).all()
+        for k, p in agent.net.state_dict().items():
+            assert torch.isfinite(p).all(), k
+    # checkpoint: reference key names, loadable into a fresh agent (ppo.py:147-149, :266-273)
+    sd = torch.load(str(tmp_path / "ck_150.pth"), weights_only=True)
+    assert sorted(sd) == sorted(["shared_net.0.weight", "shared_net.0.bias", "shared_net.2.weight", "shared_net.2.bias",
+                                 "to_mean.0.weight", "to_mean.0.bias", "to_mean.2.weight", "to_mean.2.bias",
+                                 "to_value.0.weight", "to_value.0.bias", "to_value.2.weight", "to_value.2.bias"])
+    assert sum(v.numel() for v in sd.values()) == 69587
+    args2 = make_args(4096, load=True, load_path=str(tmp_path / "ck_150.pth"), testing=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        agent2 = PPO(args2)
+    for k, p in agent2.net.state_dict().items():
+        assert torch.equal(p.cpu(), sd[k].cpu())
+    assert float(agent2.action_var[0]) == pytest.approx(0.01)             # ppo.py:152
+    _run(agent2, 5)
+    assert agent2.optim_step == 0                                         # testing: no updates (ppo.py:241)
+    agent.exit(); agent2.exit()
+
+
+def test_action_var_schedule_and_done_mask():
+    from fly_bproject_amd.ppo import PPO
+    with contextlib.redirect_stdout(io.StringIO()):
+        agent = PPO(make_args(4096))
+    _run(agent, 7)
+    np.testing.assert_allclose(float(agent.action_var[0]), 0.2 - 7e-5, rtol=1e-5)   # ppo.py:237
+    assert agent.all_done.shape == (4096, 1)                              # Q1: replaced by the last step's mask
+    assert torch.equal(agent.all_done[:, 0], 1 - agent.env.reset_buf)
+    assert torch.equal(agent.all_obs[1], agent.all_next_obs[0])           # ring aliasing
+    agent.exit()
