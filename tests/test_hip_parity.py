@@ -289,7 +289,7 @@ def test_sample_logprob_vs_reference_golden(golden, lib, tag):
     np.testing.assert_allclose(logp.cpu().numpy(), g[tag + "_logp"], rtol=2e-6, atol=2e-5)
     a2, lp2 = O.sample_logprob(g["mu"], g[tag + "_var"], g[tag + "_eps"])
     assert np.array_equal(act.cpu().numpy(), a2)
-    np.testing.assert_allclose(logp.cpu().numpy(), lp2, rtol=1e-6, atol=2e-6)
+    np.testing.assert_allclose(logp.cpu().numpy(), lp2, rtol=2e-6, atol=1e-5)   # 18 device logf vs libm
 
 
 def test_sample_logprob_full_size(lib):
@@ -304,7 +304,7 @@ def test_sample_logprob_full_size(lib):
     torch.cuda.synchronize()
     a2, lp2 = O.sample_logprob(mu, var, eps)
     assert np.array_equal(act.cpu().numpy(), a2)
-    np.testing.assert_allclose(logp.cpu().numpy(), lp2, rtol=1e-6, atol=2e-6)
+    np.testing.assert_allclose(logp.cpu().numpy(), lp2, rtol=2e-6, atol=1e-5)   # 18 device logf vs libm
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
