@@ -32,6 +32,11 @@ SYMBOLS = {
     "fly_pack_reward": [_P, C.POINTER(FlyBuffers), _I, _P],
     "ppo_sample_logprob": [_P, _P, _P, _P, _P, _L, _P],
     "ppo_td_gae": [_P, _P, _P, _P, _F, _F, _L, _L, _P, _P, _I, _P],
+    "mlp_forward": [_P, _P, _L, _P, _P, _P, _P, _P, _P, _P],
+    "mlp_grad_workspace_floats": [],
+    "mlp_backward_dx": [_P] * 10 + [_L, _F, _F, _P, _P, _P, _P, _P, _P],
+    "mlp_grad_w": [_P] * 8 + [_L, _P, _P, _P],
+    "mlp_adam_step": [_P] * 7 + [_F, _F, _F, _F, _F, _F, _P, _P],
 }
 
 
@@ -58,7 +63,7 @@ def load():
     for name, argtypes in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
         fn.argtypes = argtypes
-        fn.restype = C.c_int
+        fn.restype = C.c_int64 if name == "mlp_grad_workspace_floats" else C.c_int
     _lib = lib
     return lib
 

@@ -16,6 +16,24 @@ extern "C" hipError_t flyhip_launch_td_gae(const float* reward, const float* v, 
                                            const float* done, float gamma, float lambda, int64_t T, int64_t N,
                                            float* target_out, float* adv_out, int mode, void* stream);
 
+extern "C" hipError_t flyhip_launch_mlp_forward(const float* P, const float* x, int64_t n, float* mu_out,
+                                                float* v_out, float* out_save, float* h1_save, float* h2_save,
+                                                float* h3_save, void* stream);
+
+extern "C" hipError_t flyhip_launch_mlp_backward_dx(const float* PT, const float* out_saved, const float* h1,
+                                                    const float* h2, const float* h3, const float* action,
+                                                    const float* old_logp, const float* adv, const float* target,
+                                                    const float* var, int64_t n, float inv_batch, float clip,
+                                                    float* dz4, float* dz3, float* dz2, float* dz1, float* loss_part,
+                                                    void* stream);
+extern "C" int64_t flyhip_mlp_grad_workspace_floats(void);
+extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, const float* h2, const float* h3,
+                                               const float* dz1, const float* dz2, const float* dz3, const float* dz4,
+                                               int64_t n, float* workspace, float* grad_out, void* stream);
+extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PT, const float* G, const float* mask, float* m,
+                                             float* v, int* step, float lr, float beta1, float beta2, float eps,
+                                             float max_norm, float grad_scale, float* norm_out, void* stream);
+
 struct FlyEnv {
     FlyConfig host;
     FlyConfig* dev;
@@ -150,6 +168,60 @@ int ppo_td_gae(const float* reward, const float* v, const float* v_next, const f
     if (T <= 0 || N <= 0) return fail(FLY_E_ARG, "ppo_td_gae: T and N must be > 0");
     hipError_t e = flyhip_launch_td_gae(reward, v, v_next, done, gamma, lambda, T, N, target_out, adv_out, mode_flags, stream);
     if (e != hipSuccess) return hip_fail(e, "ppo_td_gae launch");
+    return FLY_OK;
+}
+
+int mlp_forward(const float* params, const float* x, int64_t n, float* mu_out, float* v_out,
+                float* out_save, float* h1_save, float* h2_save, float* h3_save, void* stream)
+{
+    if (!params || !x) return fail(FLY_E_ARG, "mlp_forward: null params/x");
+    if (n <= 0) return fail(FLY_E_ARG, "mlp_forward: n must be > 0");
+    if (((uintptr_t)params & 15)) return fail(FLY_E_ARG, "mlp_forward: params must be 16-byte aligned");
+    hipError_t e = flyhip_launch_mlp_forward(params, x, n, mu_out, v_out, out_save, h1_save, h2_save, h3_save, stream);
+    if (e != hipSuccess) return hip_fail(e, "mlp_forward launch");
+    return FLY_OK;
+}
+
+int64_t mlp_grad_workspace_floats(void) { return flyhip_mlp_grad_workspace_floats(); }
+
+int mlp_backward_dx(const float* params_t, const float* out_saved, const float* h1_saved,
+                    const float* h2_saved, const float* h3_saved, const float* action,
+                    const float* old_logp, const float* adv, const float* target, const float* var,
+                    int64_t n, float inv_batch, float clip, float* dz4, float* dz3, float* dz2,
+                    float* dz1, float* loss_part, void* stream)
+{
+    if (!params_t || !out_saved || !h1_saved || !h2_saved || !h3_saved || !action || !old_logp || !adv ||
+        !target || !var || !dz4 || !dz3 || !dz2 || !dz1)
+        return fail(FLY_E_ARG, "mlp_backward_dx: null pointer");
+    if (n <= 0) return fail(FLY_E_ARG, "mlp_backward_dx: n must be > 0");
+    hipError_t e = flyhip_launch_mlp_backward_dx(params_t, out_saved, h1_saved, h2_saved, h3_saved, action, old_logp,
+                                                 adv, target, var, n, inv_batch, clip, dz4, dz3, dz2, dz1, loss_part,
+                                                 stream);
+    if (e != hipSuccess) return hip_fail(e, "mlp_backward_dx launch");
+    return FLY_OK;
+}
+
+int mlp_grad_w(const float* x, const float* h1_saved, const float* h2_saved, const float* h3_saved,
+               const float* dz1, const float* dz2, const float* dz3, const float* dz4, int64_t n,
+               float* workspace, float* grad, void* stream)
+{
+    if (!x || !h1_saved || !h2_saved || !h3_saved || !dz1 || !dz2 || !dz3 || !dz4 || !workspace || !grad)
+        return fail(FLY_E_ARG, "mlp_grad_w: null pointer");
+    if (n <= 0) return fail(FLY_E_ARG, "mlp_grad_w: n must be > 0");
+    hipError_t e = flyhip_launch_mlp_grad_w(x, h1_saved, h2_saved, h3_saved, dz1, dz2, dz3, dz4, n, workspace, grad, stream);
+    if (e != hipSuccess) return hip_fail(e, "mlp_grad_w launch");
+    return FLY_OK;
+}
+
+int mlp_adam_step(float* params, float* params_t, const float* grad, const float* mask, float* exp_avg,
+                  float* exp_avg_sq, int32_t* step, float lr, float beta1, float beta2, float eps,
+                  float max_norm, float grad_scale, float* norm_out, void* stream)
+{
+    if (!params || !params_t || !grad || !mask || !exp_avg || !exp_avg_sq || !step)
+        return fail(FLY_E_ARG, "mlp_adam_step: null pointer");
+    hipError_t e = flyhip_launch_mlp_adam(params, params_t, grad, mask, exp_avg, exp_avg_sq, step, lr, beta1, beta2,
+                                          eps, max_norm, grad_scale, norm_out, stream);
+    if (e != hipSuccess) return hip_fail(e, "mlp_adam_step launch");
     return FLY_OK;
 }
 

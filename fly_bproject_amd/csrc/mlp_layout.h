@@ -1,0 +1,46 @@
+// mlp_layout.h — packed parameter layout of the actor-critic network (reference ppo.py:10-102)
+// shared by the MFMA kernels (mlp_mfma.hip) and mirrored by fly_bproject_amd/policy.py.
+//
+// One flat fp32 buffer `P` (MLP_PACKED_FLOATS) holds every layer as a row-major [N][K] matrix
+// (torch's nn.Linear weight orientation), K padded to a multiple of 8 so that each lane's
+// MFMA B-fragment is four consecutive floats (one 16-byte load):
+//
+//   L1  shared_net.0   W1 [256][80]   cols 0..72 = weight [256][73], cols 73..79 = 0      b1 [256]
+//   L2  shared_net.2   W2 [128][256]                                                       b2 [128]
+//   L3  to_mean.0 | to_value.0 stacked: W3 [128][128], rows 0..63 actor, 64..127 critic    b3 [128]
+//   L4  to_mean.2 / to_value.2 as one [32][128] matrix over the concatenated (a1 | c1):
+//         rows 0..17  = [ to_mean.2.weight [18][64] | 0 ]
+//         row  18     = [ 0 | to_value.2.weight [1][64] ]
+//         rows 19..31 = 0                                                                   b4 [32]
+//   The torch-visible parameters are strided views into this buffer, so there is one copy of truth.
+//   Structural zeros stay zero because their gradients are masked (policy.py).
+//
+// A second buffer `PT` (MLP_PACKED_T_FLOATS) holds the transposes the backward pass streams:
+//   Wt2 [256][128], Wt3 [128][128], Wt4 [128][32].
+#ifndef MLP_LAYOUT_H
+#define MLP_LAYOUT_H
+
+#define MLP_IN 73
+#define MLP_IN_PAD 80
+#define MLP_H1 256
+#define MLP_H2 128
+#define MLP_H3 128      /* 64 actor + 64 critic */
+#define MLP_OUT 32      /* 18 means + 1 value + 13 pad */
+#define MLP_NACT 18
+
+#define MLP_OFF_W1 0
+#define MLP_OFF_B1 (MLP_OFF_W1 + MLP_H1 * MLP_IN_PAD)      /* 20480 */
+#define MLP_OFF_W2 (MLP_OFF_B1 + MLP_H1)                   /* 20736 */
+#define MLP_OFF_B2 (MLP_OFF_W2 + MLP_H2 * MLP_H1)          /* 53504 */
+#define MLP_OFF_W3 (MLP_OFF_B2 + MLP_H2)                   /* 53632 */
+#define MLP_OFF_B3 (MLP_OFF_W3 + MLP_H3 * MLP_H2)          /* 70016 */
+#define MLP_OFF_W4 (MLP_OFF_B3 + MLP_H3)                   /* 70144 */
+#define MLP_OFF_B4 (MLP_OFF_W4 + MLP_OUT * MLP_H3)         /* 74240 */
+#define MLP_PACKED_FLOATS (MLP_OFF_B4 + MLP_OUT)           /* 74272 */
+
+#define MLP_OFF_WT2 0
+#define MLP_OFF_WT3 (MLP_OFF_WT2 + MLP_H1 * MLP_H2)        /* 32768 */
+#define MLP_OFF_WT4 (MLP_OFF_WT3 + MLP_H2 * MLP_H3)        /* 49152 */
+#define MLP_PACKED_T_FLOATS (MLP_OFF_WT4 + MLP_H3 * MLP_OUT) /* 53248 */
+
+#endif

@@ -38,10 +38,16 @@ class Net(nn.Module):
         self.to_mean = nn.Sequential(nn.Linear(128, 64), nn.ELU(), nn.Linear(64, num_act), nn.ELU())
         self.to_value = nn.Sequential(nn.Linear(128, 64), nn.ELU(), nn.Linear(64, 1))
 
+    _policy = None      # PackedPolicy, attached by PPO: inference then runs on the MFMA kernel
+
     def pi(self, x):
+        if self._policy is not None and not torch.is_grad_enabled():
+            return self._policy.forward(x, want_mu=True, want_v=False)[0]
         return self.to_mean(self.shared_net(x))
 
     def v(self, x):
+        if self._policy is not None and not torch.is_grad_enabled():
+            return self._policy.forward(x, want_mu=False, want_v=True)[1]
         return self.to_value(self.shared_net(x))
 
 
@@ -102,6 +108,9 @@ class PPO:
         if getattr(self.args, "load", False):                       # ppo.py:147-149
             print("loaded from: ", str(self.args.load_path))
             self.net.load_state_dict(torch.load(self.args.load_path, map_location=dev, weights_only=True))
+        from .policy import PackedPolicy
+        self.policy = PackedPolicy(self.net, dev)                   # parameters become views of one packed buffer
+        self.net._policy = self.policy
         action_var = 0.01 if self.args.testing else 0.2             # ppo.py:152
         self.action_var = torch.full((self.env.num_act,), action_var, device=dev)
         self.optim = torch.optim.Adam(self.net.parameters(), lr=self.lr)
@@ -227,7 +236,8 @@ class PPO:
         if int(getattr(self.args, "rank", 0)) != 0:
             return
         path = self.args.save_path + endofname + ".pth"
-        torch.save(self.net.state_dict(), path)
+        # parameters are views of the packed buffer: save compact, contiguous copies
+        torch.save({k: v.detach().clone().contiguous() for k, v in self.net.state_dict().items()}, path)
 
     def generate_video(self):
         self.env.generate_video()

@@ -164,6 +164,48 @@ int ppo_td_gae(const float* reward, const float* v, const float* v_next, const f
                float gamma, float lambda, int64_t T, int64_t N,
                float* target_out, float* adv_out, int mode_flags, void* stream);
 
+/*
+ * Actor-critic MLP on the matrix cores (fp32-in/fp32-accumulate MFMA), reference ppo.py:10-102
+ * (`Net.pi` / `Net.v`; 73-256-128 shared trunk, 128-64-18 actor with ELU on the mean, 128-64-1
+ * critic).  `params` is the packed buffer of MLP_PACKED_FLOATS floats laid out as documented in
+ * fly_bproject_amd/csrc/mlp_layout.h.  x f32 [n][73].  Every output pointer is optional (NULL):
+ *   mu_out [n][18]  actor mean (after its ELU)        v_out [n]  critic value
+ *   out_save [n][32], h1_save [n][256], h2_save [n][128], h3_save [n][128]: activations kept
+ *   for the backward pass.
+ */
+#define MLP_PACKED_FLOATS_ABI 74272
+#define MLP_PACKED_T_FLOATS_ABI 53248
+int mlp_forward(const float* params, const float* x, int64_t n, float* mu_out, float* v_out,
+                float* out_save, float* h1_save, float* h2_save, float* h3_save, void* stream);
+
+
+/*
+ * One PPO minibatch backward (ppo.py:184-197), three launches on the saved activations of
+ * mlp_forward (n rows = the minibatch; inv_batch = 1/n of the GLOBAL minibatch):
+ *   mlp_backward_dx : loss gradient at the outputs (clipped surrogate with torch's subgradient
+ *                     conventions + scalar-mean Huber, ppo.py:191-194) and the dX chain;
+ *                     writes dz4 [n][32], dz3 [n][128], dz2 [n][128], dz1 [n][256] and
+ *                     loss_part [ceil(n/32)][2] (sum of -min(surr1,surr2), sum of huber).
+ *   mlp_grad_w      : dW = dZ^T A and db = colsum(dZ) for all four layers into `grad`
+ *                     (packed layout of `params`); `workspace` holds
+ *                     mlp_grad_workspace_floats() floats.
+ *   mlp_adam_step   : grad *= grad_scale; clip_grad_norm_(max_norm); Adam with torch defaults;
+ *                     refreshes params_t (the transposed weights).  `mask` (packed layout, 0/1)
+ *                     freezes padding and structural zeros.  `step` is a device int counter.
+ */
+int64_t mlp_grad_workspace_floats(void);
+int mlp_backward_dx(const float* params_t, const float* out_saved, const float* h1_saved,
+                    const float* h2_saved, const float* h3_saved, const float* action,
+                    const float* old_logp, const float* adv, const float* target, const float* var,
+                    int64_t n, float inv_batch, float clip, float* dz4, float* dz3, float* dz2,
+                    float* dz1, float* loss_part, void* stream);
+int mlp_grad_w(const float* x, const float* h1_saved, const float* h2_saved, const float* h3_saved,
+               const float* dz1, const float* dz2, const float* dz3, const float* dz4, int64_t n,
+               float* workspace, float* grad, void* stream);
+int mlp_adam_step(float* params, float* params_t, const float* grad, const float* mask, float* exp_avg,
+                  float* exp_avg_sq, int32_t* step, float lr, float beta1, float beta2, float eps,
+                  float max_norm, float grad_scale, float* norm_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,3 +61,46 @@ def test_action_var_schedule_and_done_mask():
     assert torch.equal(agent.all_done[:, 0], 1 - agent.env.reset_buf)
     assert torch.equal(agent.all_obs[1], agent.all_next_obs[0])           # ring aliasing
     agent.exit()
+
+
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 8192, 40960 + 7])
+def test_mfma_forward_matches_torch_and_oracle(golden, n):
+    """mlp_forward (fp32 MFMA) vs torch fp32 on the same weights; tolerance 2e-5 rel/abs (k-order and
+    fma chaining differ from a BLAS dot product, nothing else), and vs the reference's own Net.pi/.v
+    outputs recorded in g4."""
+    from fly_bproject_amd.policy import PackedPolicy
+    from fly_bproject_amd.ppo import Net
+    g = golden("g4_net")
+    net = Net(73, 18).to("cuda:0")
+    net.load_state_dict({k: torch.from_numpy(g[k]) for k in g.files if "." in k})
+    ref = Net(73, 18).to("cuda:0")
+    ref.load_state_dict(net.state_dict())
+    pol = PackedPolicy(net, "cuda:0")
+    net._policy = pol
+    gen = torch.Generator(device="cuda:0").manual_seed(n)
+    x = torch.randn(n, 73, device="cuda:0", generator=gen) * 1.5
+    with torch.no_grad():
+        mu, v = net.pi(x), net.v(x)                       # MFMA path (no grad)
+        mu_t, v_t = ref.to_mean(ref.shared_net(x)), ref.to_value(ref.shared_net(x))
+    torch.testing.assert_close(mu, mu_t, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(v, v_t, rtol=2e-5, atol=2e-5)
+    if n == 8192:
+        xg = torch.from_numpy(g["x"]).to("cuda:0")
+        with torch.no_grad():
+            np.testing.assert_allclose(net.pi(xg).cpu().numpy(), g["pi"], rtol=2e-5, atol=2e-5)
+            np.testing.assert_allclose(net.v(xg).cpu().numpy(), g["v"], rtol=2e-5, atol=2e-5)
+        saves = {"out": torch.empty(n, 32, device="cuda:0"), "h1": torch.empty(n, 256, device="cuda:0"),
+                 "h2": torch.empty(n, 128, device="cuda:0"), "h3": torch.empty(n, 128, device="cuda:0")}
+        pol.forward(x, saves=saves)
+        with torch.no_grad():
+            h1 = ref.shared_net[1](ref.shared_net[0](x)); h2 = ref.shared_net(x)
+            h3 = torch.cat([ref.to_mean[1](ref.to_mean[0](h2)), ref.to_value[1](ref.to_value[0](h2))], dim=1)
+        torch.testing.assert_close(saves["h1"], h1, rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(saves["h2"], h2, rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(saves["h3"], h3, rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(saves["out"][:, :18], mu_t, rtol=2e-5, atol=2e-5)
+        assert torch.all(saves["out"][:, 19:] == 0)
+        # determinism
+        mu2 = net.pi(x) if not torch.is_grad_enabled() else None
+        with torch.no_grad():
+            assert torch.equal(net.pi(x), mu)
