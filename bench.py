@@ -50,28 +50,88 @@ def quiet():
     return contextlib.redirect_stdout(io.StringIO())
 
 
-def kernel_roofline(num_envs, reps):
-    """Average duration of the dominant env kernel (fly_step, one launch per env step), measured
-    with HIP events on the stream it is launched on (torch's current stream)."""
-    from fly_bproject_amd.fly import Fly
-    env = Fly(make_args(num_envs))
-    a = torch.zeros(num_envs, 18, device="cuda:0").uniform_(-1, 1)
-    for _ in range(20):
-        env.step(a)
+def _time_launches(fn, reps):
+    """Average duration of `fn` (one kernel launch) from HIP events on the launch stream."""
+    for _ in range(10):
+        fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        env.step(a)
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    dur_s = e0.elapsed_time(e1) * 1e-3 / reps
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+# algorithmic work per unit (DESIGN.md section 3): bytes per env-step / FLOP per sample
+MLP_FWD_FLOP = 2 * (73 * 256 + 256 * 128 + 128 * 64 * 2 + 64 * 18 + 64)        # 138 112
+MLP_BWD_DX_FLOP = 2 * (64 * 18 + 64 + 128 * 128 + 128 * 256)                   # 100 736
+MLP_GRAD_W_FLOP = MLP_FWD_FLOP
+PEAK_HBM_GBS, PEAK_F32_MFMA_TFLOPS = 8000.0, 157.3                             # MI355X_MICROARCH.md
+
+
+def kernel_rooflines(num_envs, T, reps):
+    """Per-kernel roofline entries, each measured live with HIP events; the dominant kernel (largest
+    share of one PPO iteration) is returned first."""
+    import ctypes as C
+    from fly_bproject_amd import _lib
+    from fly_bproject_amd.fly import Fly
+    from fly_bproject_amd.policy import PackedPolicy
+    from fly_bproject_amd.ppo import Net
+    lib = _lib.load()
+    env = Fly(make_args(num_envs))
+    a = torch.zeros(num_envs, 18, device="cuda:0").uniform_(-1, 1)
+    t_step = _time_launches(lambda: env.step(a), reps)
     env.exit()
-    achieved = FUSED_STEP_BYTES_PER_ENV * num_envs / dur_s / 1e9
-    return {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-            "frac": round(achieved / 8000.0, 5), "traffic": None, "kernel": "fly_kernel<63> (fly_step)",
-            "avg_launch_us": round(dur_s * 1e6, 3),
-            "algorithmic_bytes_per_launch": FUSED_STEP_BYTES_PER_ENV * num_envs}
+    rows = (40960 // num_envs) * num_envs
+    net = Net(73, 18).to("cuda:0")
+    pol = PackedPolicy(net, "cuda:0")
+    pol.init_training(rows)
+    x = torch.randn(rows, 73, device="cuda:0")
+    act = torch.rand(rows, 18, device="cuda:0") * 2 - 1
+    olp = torch.randn(rows, device="cuda:0") - 20
+    adv = torch.randn(rows, device="cuda:0"); tgt = torch.randn(rows, device="cuda:0")
+    var = torch.full((18,), 0.2, device="cuda:0")
+    p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    s, d = pol.saves, pol.dz
+    pol.minibatch_grad(x, act, olp, adv, tgt, var, 0.2)
+    t_fwd = _time_launches(lambda: lib.mlp_forward(p(pol.P), p(x), rows, None, None, p(s["out"]), p(s["h1"]),
+                                                    p(s["h2"]), p(s["h3"]), _lib.stream_ptr()), reps)
+    t_bwd = _time_launches(lambda: lib.mlp_backward_dx(p(pol.PT), p(s["out"]), p(s["h1"]), p(s["h2"]), p(s["h3"]),
+                                                       p(act), p(olp), p(adv), p(tgt), p(var), rows, 1.0 / rows, 0.2,
+                                                       p(d["dz4"]), p(d["dz3"]), p(d["dz2"]), p(d["dz1"]),
+                                                       p(pol.loss_part), _lib.stream_ptr()), reps)
+    t_gw = _time_launches(lambda: lib.mlp_grad_w(p(x), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(d["dz1"]), p(d["dz2"]),
+                                                 p(d["dz3"]), p(d["dz4"]), rows, p(pol.workspace), p(pol.G),
+                                                 _lib.stream_ptr()), reps)
+    t_adam = _time_launches(lambda: pol.adam_step(), reps)
+
+    def hbm(name, dur, bytes_per_launch, per_iter):
+        ach = bytes_per_launch / dur / 1e9
+        return {"kernel": name, "bound": "hbm", "achieved": round(ach, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(ach / PEAK_HBM_GBS, 5), "traffic": None, "avg_launch_us": round(dur * 1e6, 3),
+                "algorithmic_per_launch": bytes_per_launch, "launches_per_iteration": per_iter,
+                "iteration_share_ms": round(dur * per_iter * 1e3, 3)}
+
+    def mfma(name, dur, flop_per_launch, per_iter):
+        ach = flop_per_launch / dur / 1e12
+        return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5), "traffic": None,
+                "avg_launch_us": round(dur * 1e6, 3), "algorithmic_per_launch": flop_per_launch,
+                "launches_per_iteration": per_iter, "iteration_share_ms": round(dur * per_iter * 1e3, 3)}
+
+    critic_rows = (T + 1) * num_envs
+    fwd_equiv_launches = 75 + critic_rows / rows + T * num_envs / rows      # update + critic pass + rollout policy
+    ks = [
+        hbm("fly_kernel<63> (fly_step)", t_step, FUSED_STEP_BYTES_PER_ENV * num_envs, T),
+        mfma("mlp_forward_kernel", t_fwd, MLP_FWD_FLOP * rows, round(fwd_equiv_launches, 2)),
+        mfma("mlp_backward_dx_kernel", t_bwd, MLP_BWD_DX_FLOP * rows, 75),
+        mfma("mlp_grad_w_kernel (+reduce)", t_gw, MLP_GRAD_W_FLOP * rows, 75),
+        hbm("mlp_adam_kernel", t_adam, 74272 * 4 * 7, 75),
+    ]
+    ks.sort(key=lambda k: -k["iteration_share_ms"])
+    return ks
 
 
 def cpu_baseline(num_envs):
@@ -82,8 +142,9 @@ def cpu_baseline(num_envs):
     import numpy as np
     from oracle import oracle as O
     from oracle import ppo_oracle as PO
-    cores = os.cpu_count() or 1
+    cores = min(16, os.cpu_count() or 1)      # the host share of one GPU on the box
     torch.set_num_threads(cores)
+    O.set_threads(cores)
     T = 16 * (40960 // num_envs)
     cfg = O.default_config(num_envs)
     s = O.EnvState(num_envs)
@@ -195,7 +256,9 @@ def main():
             "rollout_only_env_steps_per_s": round(world * a.num_envs * T / rollout_s, 1),
             "params_finite": finite,
         }
-        line["roofline"] = kernel_roofline(a.num_envs, a.kernel_reps)
+        ks = kernel_rooflines(a.num_envs, T, a.kernel_reps)
+        line["roofline"] = ks[0]                     # the dominant kernel of one iteration
+        line["kernels"] = ks[1:]
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.num_envs)
         print(json.dumps(line), flush=True)

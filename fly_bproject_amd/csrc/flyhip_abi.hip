@@ -34,6 +34,10 @@ extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PT, const float* G
                                              float* v, int* step, float lr, float beta1, float beta2, float eps,
                                              float max_norm, float grad_scale, float* norm_out, void* stream);
 
+extern "C" hipError_t flyhip_launch_bookkeeping(const float* reward, int64_t n, float* score_acc, float score_scale,
+                                                float* action_var, int nvar, float var_decay, float var_min,
+                                                void* stream);
+
 struct FlyEnv {
     FlyConfig host;
     FlyConfig* dev;
@@ -168,6 +172,16 @@ int ppo_td_gae(const float* reward, const float* v, const float* v_next, const f
     if (T <= 0 || N <= 0) return fail(FLY_E_ARG, "ppo_td_gae: T and N must be > 0");
     hipError_t e = flyhip_launch_td_gae(reward, v, v_next, done, gamma, lambda, T, N, target_out, adv_out, mode_flags, stream);
     if (e != hipSuccess) return hip_fail(e, "ppo_td_gae launch");
+    return FLY_OK;
+}
+
+int ppo_step_bookkeeping(const float* reward, int64_t n, float* score_acc, float score_scale,
+                         float* action_var, int32_t nvar, float var_decay, float var_min, void* stream)
+{
+    if (!reward || !score_acc || !action_var) return fail(FLY_E_ARG, "ppo_step_bookkeeping: null pointer");
+    if (n <= 0 || nvar < 0 || nvar > 256) return fail(FLY_E_ARG, "ppo_step_bookkeeping: bad size");
+    hipError_t e = flyhip_launch_bookkeeping(reward, n, score_acc, score_scale, action_var, nvar, var_decay, var_min, stream);
+    if (e != hipSuccess) return hip_fail(e, "ppo_step_bookkeeping launch");
     return FLY_OK;
 }
 

@@ -98,6 +98,15 @@ class Fly:
         self.obs_buf = rows
         self._bufs.obs = rows.data_ptr()
 
+    def bind_reward(self, row):
+        """Make `row` (f32 [N], contiguous) the reward buffer (a row of the caller's rollout)."""
+        if row.numel() != self.reward_buf.numel() or row.dtype != torch.float32 or not row.is_contiguous():
+            raise ValueError("bind_reward needs a contiguous f32 tensor of %d elements" % self.reward_buf.numel())
+        if row.device != self.reward_buf.device:
+            raise ValueError("bind_reward: wrong device")
+        self.reward_buf = row.view(-1)
+        self._bufs.reward = row.data_ptr()
+
     def _check_actions(self, actions):
         n = self.args.num_envs
         if actions.shape != (n, NUM_DOF) or actions.dtype != torch.float32 or actions.device != self.device:

@@ -87,3 +87,54 @@ class PackedPolicy:
                                          ptr(s.get("h1")), ptr(s.get("h2")), ptr(s.get("h3")), _lib.stream_ptr()),
                    "mlp_forward")
         return (mu.view(*lead, NACT) if want_mu else None), (v.view(*lead, 1) if want_v else None)
+
+    # ---- training on the MFMA kernels (ppo.py:184-199) ------------------------------------------
+    def init_training(self, max_rows, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0):
+        dev = self.device
+        self.lr, self.betas, self.eps, self.max_norm = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(max_norm)
+        self.G = torch.zeros(PACKED, device=dev)
+        self.exp_avg = torch.zeros(PACKED, device=dev)
+        self.exp_avg_sq = torch.zeros(PACKED, device=dev)
+        self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.grad_norm = torch.zeros(1, device=dev)
+        self.workspace = torch.empty(int(self._lib.mlp_grad_workspace_floats()), device=dev)
+        self.max_rows = int(max_rows)
+        r = self.max_rows
+        self.saves = {"out": torch.empty(r, OUT, device=dev), "h1": torch.empty(r, H1, device=dev),
+                      "h2": torch.empty(r, H2, device=dev), "h3": torch.empty(r, H3, device=dev)}
+        self.dz = {"dz4": torch.empty(r, OUT, device=dev), "dz3": torch.empty(r, H3, device=dev),
+                   "dz2": torch.empty(r, H2, device=dev), "dz1": torch.empty(r, H1, device=dev)}
+        self.loss_part = torch.zeros((r + 31) // 32, 2, device=dev)
+
+    def minibatch_grad(self, x, action, old_logp, adv, target, var, clip, global_rows=None):
+        """Forward + loss + backward of one minibatch; leaves the packed gradient in `self.G`."""
+        n = x.shape[0]
+        assert n <= self.max_rows and x.is_contiguous() and action.is_contiguous()
+        for t in (old_logp, adv, target):
+            assert t.is_contiguous() and t.numel() == n
+        s, d = self.saves, self.dz
+        p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+        st = _lib.stream_ptr()
+        _lib.check(self._lib.mlp_forward(p(self.P), p(x), C.c_int64(n), None, None, p(s["out"]), p(s["h1"]),
+                                         p(s["h2"]), p(s["h3"]), st), "mlp_forward")
+        inv_b = 1.0 / float(global_rows if global_rows else n)
+        _lib.check(self._lib.mlp_backward_dx(p(self.PT), p(s["out"]), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(action),
+                                             p(old_logp), p(adv), p(target), p(var), C.c_int64(n), C.c_float(inv_b),
+                                             C.c_float(clip), p(d["dz4"]), p(d["dz3"]), p(d["dz2"]), p(d["dz1"]),
+                                             p(self.loss_part), st), "mlp_backward_dx")
+        _lib.check(self._lib.mlp_grad_w(p(x), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(d["dz1"]), p(d["dz2"]),
+                                        p(d["dz3"]), p(d["dz4"]), C.c_int64(n), p(self.workspace), p(self.G), st),
+                   "mlp_grad_w")
+
+    def loss_value(self, n):
+        """ppo.py:194/:197 scalar of the last minibatch_grad call (diagnostics; one small reduction)."""
+        parts = self.loss_part[: (n + 31) // 32].sum(0)
+        return (parts[0] + parts[1]) / n
+
+    def adam_step(self, grad_scale=1.0):
+        p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+        _lib.check(self._lib.mlp_adam_step(p(self.P), p(self.PT), p(self.G), p(self.grad_mask), p(self.exp_avg),
+                                           p(self.exp_avg_sq), p(self.step), C.c_float(self.lr),
+                                           C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
+                                           C.c_float(self.max_norm), C.c_float(grad_scale), p(self.grad_norm),
+                                           _lib.stream_ptr()), "mlp_adam_step")

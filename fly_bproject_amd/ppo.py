@@ -92,7 +92,7 @@ class PPO:
         self.all_next_obs = self._obs_ring[1:]
         self.all_acts = torch.zeros((T, n, self.num_acts), device=dev)
         self.all_reward = torch.zeros((T, n, 1), device=dev)
-        self.all_done = torch.zeros((T, n, 1), device=dev)
+        self._all_done = None                                        # see the all_done property (Q1)
         self.all_log_prob = torch.zeros((T, n), device=dev)
         self.all_advantage = torch.zeros((T, n, 1), device=dev)
         self._target = torch.zeros((T, n, 1), device=dev)
@@ -111,6 +111,9 @@ class PPO:
         from .policy import PackedPolicy
         self.policy = PackedPolicy(self.net, dev)                   # parameters become views of one packed buffer
         self.net._policy = self.policy
+        # "hip": MFMA forward/backward + fused clip/Adam kernels; "torch": torch-ROCm autograd (A/B reference)
+        self.update_backend = getattr(args, "update_backend", "hip")
+        self.policy.init_training(self.mini_chunk_size * n, lr=self.lr)
         action_var = 0.01 if self.args.testing else 0.2             # ppo.py:152
         self.action_var = torch.full((self.env.num_act,), action_var, device=dev)
         self.optim = torch.optim.Adam(self.net.parameters(), lr=self.lr)
@@ -123,6 +126,19 @@ class PPO:
         if self.world_size > 1:
             from .dist import FlatGradAllReduce
             self._flat_grad = FlatGradAllReduce(self.net.parameters(), self.world_size)
+
+    # ppo.py:230 replaces the whole [T,N,1] buffer by the LAST step's [N,1] mask after every step
+    # (Q1).  reset_buf only changes inside env.step, so deriving the mask on demand is the same
+    # thing without two tiny launches per step; an explicit assignment (tests) overrides it.
+    @property
+    def all_done(self):
+        if self._all_done is not None:
+            return self._all_done
+        return (1 - self.env.reset_buf).unsqueeze(-1)
+
+    @all_done.setter
+    def all_done(self, value):
+        self._all_done = value
 
     # ------------------------------------------------------------------------------------------
     def make_data(self):
@@ -160,6 +176,8 @@ class PPO:
         """ppo.py:173-202: 5 epochs x 15 contiguous-in-T minibatches; the 16th chunk is never
         visited (Q3).  With world_size > 1 the flat gradient is all-reduced (mean) before the clip."""
         obs, action, old_log_prob, target, advantage = self.make_data()
+        if self.update_backend == "hip":
+            return self._update_hip(obs, action, old_log_prob, target, advantage)
         for _ in range(self.epoch):
             k = 0
             for j in range(self.mini_chunk_size, self.rollout_size, self.mini_chunk_size):
@@ -173,6 +191,27 @@ class PPO:
                     self._flat_grad.allreduce_mean()
                 nn.utils.clip_grad_norm_(self.net.parameters(), 1.0)
                 self.optim.step()
+                self.optim_step += 1
+                k = j
+
+    def _update_hip(self, obs, action, old_log_prob, target, advantage):
+        """ppo.py:179-202 on the MFMA kernels: per minibatch one fused forward, the loss gradient +
+        dX chain, the split-row dW, (world_size > 1: ONE all-reduce of the packed gradient), and
+        the fused clip + Adam step.  Minibatches are contiguous slices of the rollout, so no
+        gather/copy happens."""
+        import torch.distributed as dist
+        mc, n = self.mini_chunk_size, int(self.args.num_envs)
+        rows = mc * n
+        pol = self.policy
+        for _ in range(self.epoch):
+            k = 0
+            for j in range(mc, self.rollout_size, mc):
+                pol.minibatch_grad(obs[k:j].view(rows, self.num_obs), action[k:j].view(rows, self.num_acts),
+                                   old_log_prob[k:j].view(rows), advantage[k:j].view(rows),
+                                   target[k:j].view(rows), self.action_var, self.clip)
+                if self.world_size > 1:
+                    dist.all_reduce(pol.G, op=dist.ReduceOp.SUM)    # 297 KB, latency-bound on xGMI
+                pol.adam_step(grad_scale=1.0 / self.world_size)
                 self.optim_step += 1
                 k = j
 
@@ -194,14 +233,15 @@ class PPO:
                 "ppo_sample_logprob")
 
             self.env.bind_obs(self._obs_ring[t + 1])                # next_obs row (ppo.py:228)
+            self.env.bind_reward(self.all_reward[t])                # reward row (ppo.py:229)
             self.env.step(action)                                   # ppo.py:223
-
-            self.all_reward[t] = self.env.reward_buf.unsqueeze(-1)  # ppo.py:229
-            self.all_done = (1 - self.env.reset_buf).unsqueeze(-1)  # ppo.py:230 (Q1: replaces the buffer)
-            self._score_acc += self.env.reward_buf.mean() / self.num_eval_freq   # ppo.py:233, on device
-
-            if not self.args.testing:                               # ppo.py:236-237
-                self.action_var = torch.clamp(self.action_var - 0.00001, min=0.01)
+            # ppo.py:230 (all_done): see the property.  ppo.py:233 + :236-237 in one tiny launch:
+            _lib.check(self._lib.ppo_step_bookkeeping(
+                C.c_void_p(self.env.reward_buf.data_ptr()), C.c_int64(self.env.reward_buf.numel()),
+                C.c_void_p(self._score_acc.data_ptr()), C.c_float(1.0 / self.num_eval_freq),
+                C.c_void_p(self.action_var.data_ptr()), C.c_int(self.num_acts),
+                C.c_float(0.0 if self.args.testing else 0.00001), C.c_float(0.01), _lib.stream_ptr()),
+                "ppo_step_bookkeeping")
 
         if t + 1 == self.rollout_size:                              # ppo.py:240-252
             if not self.args.testing:

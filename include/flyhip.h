@@ -164,6 +164,11 @@ int ppo_td_gae(const float* reward, const float* v, const float* v_next, const f
                float gamma, float lambda, int64_t T, int64_t N,
                float* target_out, float* adv_out, int mode_flags, void* stream);
 
+/* ppo.py:233 and :237 without the per-step host sync: *score_acc += mean(reward) * score_scale;
+ * action_var[j] = max(var_min, action_var[j] - var_decay) (skipped when var_decay <= 0). */
+int ppo_step_bookkeeping(const float* reward, int64_t n, float* score_acc, float score_scale,
+                         float* action_var, int32_t nvar, float var_decay, float var_min, void* stream);
+
 /*
  * Actor-critic MLP on the matrix cores (fp32-in/fp32-accumulate MFMA), reference ppo.py:10-102
  * (`Net.pi` / `Net.v`; 73-256-128 shared trunk, 128-64-18 actor with ELU on the mean, 128-64-1

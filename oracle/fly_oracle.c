@@ -7,6 +7,19 @@
 #include "fly_oracle.h"
 #include <math.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* cpu_baseline leg: bound the OpenMP team to the host share of one GPU */
+void orc_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 
 /* ---- K3 physics, build-defined (two precisions) ---------------------------------------- */
 #define REAL float

@@ -64,6 +64,7 @@ typedef struct OrcConfig {
     float termination_height_up;
 } OrcConfig;
 
+void orc_set_threads(int n);
 /* fly.py:626-657 */
 void orc_scale_actions(const OrcConfig* c, const float* actions, float* targets, int64_t n);
 /* fly.py:446-480; returns number of envs reset */

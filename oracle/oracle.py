@@ -30,6 +30,10 @@ def lib():
     return _LIB
 
 
+def set_threads(n):
+    lib().orc_set_threads(C.c_int(int(n)))
+
+
 def _p(a, ty=C.c_float):
     return a.ctypes.data_as(C.POINTER(ty)) if a is not None else None
 
