@@ -32,7 +32,7 @@ extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, 
                                                int64_t n, float* workspace, float* grad_out, void* stream);
 extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PT, const float* G, const float* mask, float* m,
                                              float* v, int* step, float lr, float beta1, float beta2, float eps,
-                                             float max_norm, float grad_scale, float* norm_out, void* stream);
+                                             float max_norm, float grad_scale, float* norm_ws, void* stream);
 
 extern "C" hipError_t flyhip_launch_bookkeeping(const float* reward, int64_t n, float* score_acc, float score_scale,
                                                 float* action_var, int nvar, float var_decay, float var_min,
@@ -229,12 +229,12 @@ int mlp_grad_w(const float* x, const float* h1_saved, const float* h2_saved, con
 
 int mlp_adam_step(float* params, float* params_t, const float* grad, const float* mask, float* exp_avg,
                   float* exp_avg_sq, int32_t* step, float lr, float beta1, float beta2, float eps,
-                  float max_norm, float grad_scale, float* norm_out, void* stream)
+                  float max_norm, float grad_scale, float* norm_ws, void* stream)
 {
-    if (!params || !params_t || !grad || !mask || !exp_avg || !exp_avg_sq || !step)
+    if (!params || !params_t || !grad || !mask || !exp_avg || !exp_avg_sq || !step || !norm_ws)
         return fail(FLY_E_ARG, "mlp_adam_step: null pointer");
     hipError_t e = flyhip_launch_mlp_adam(params, params_t, grad, mask, exp_avg, exp_avg_sq, step, lr, beta1, beta2,
-                                          eps, max_norm, grad_scale, norm_out, stream);
+                                          eps, max_norm, grad_scale, norm_ws, stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_adam_step launch");
     return FLY_OK;
 }

@@ -31,7 +31,9 @@ constexpr int BM = 32;          // rows per workgroup
 constexpr int NWAVE = 4;
 constexpr int THREADS = 64 * NWAVE;
 
-__device__ __forceinline__ float elu(float x) { return x > 0.0f ? x : expm1f(x); }
+// ELU as torch evaluates it: x > 0 ? x : exp(x) - 1 (ELU.cpp), with the hardware exp2 path
+// (v_exp_f32, ~1 ulp on exp): absolute error vs expm1 <= ~1.2e-7, inside the stated 2e-5 tolerance.
+__device__ __forceinline__ float elu(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
 // derivative of ELU expressed through its OUTPUT y: 1 for y > 0, y + 1 otherwise
 __device__ __forceinline__ float elu_grad_from_out(float y) { return y > 0.0f ? 1.0f : y + 1.0f; }
 
@@ -74,23 +76,33 @@ __device__ __forceinline__ void tile_gemm(const float* __restrict__ W, int col0,
 // C/D layout of the 32x32 tile: lane holds column (lane&31), rows (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-// bias + ELU epilogue: writes the activation tile to LDS (next layer's A operand) and, when
-// `save` is non-null, to global [rows][N] for the backward pass.
+// bias + ELU epilogue: writes the activation tile to LDS (the next layer's A operand).
 template <int N, int NT>
 __device__ __forceinline__ void epilogue_elu(const f32x16 (&acc)[NT], const float* __restrict__ bias, int col0,
-                                             float* lds_out, float* __restrict__ save, long row0, long nrows, int lane)
+                                             float* lds_out, int lane)
 {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int col = col0 + 32 * t + (lane & 31);
         const float bv = bias[col];
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row = acc_row(reg, lane);
-            const float y = elu(acc[t][reg] + bv);
-            lds_out[row * (N + 4) + col] = y;
-            if (save && row0 + row < nrows) save[(row0 + row) * N + col] = y;
-        }
+        for (int reg = 0; reg < 16; ++reg)
+            lds_out[acc_row(reg, lane) * (N + 4) + col] = elu(acc[t][reg] + bv);
+    }
+}
+
+// Copy a finished [32][N] tile from LDS (pitch N+4) to global [rows][N]: the tile is one contiguous
+// block of 32*N floats in HBM, written with 16-byte stores by the whole workgroup.
+template <int N>
+__device__ __forceinline__ void copy_tile_out(const float* lds_tile, float* __restrict__ dst, long row0, long nrows, int tid)
+{
+    if (!dst) return;
+#pragma unroll
+    for (int i = tid; i < BM * N / 4; i += THREADS) {
+        const int row = i / (N / 4), c4 = i - row * (N / 4);
+        if (row0 + row < nrows)
+            *reinterpret_cast<float4*>(dst + (row0 + row) * N + 4 * c4) =
+                *reinterpret_cast<const float4*>(lds_tile + row * (N + 4) + 4 * c4);
     }
 }
 
@@ -136,23 +148,26 @@ __global__ __launch_bounds__(THREADS) void mlp_forward_kernel(
         f32x16 acc[2];
         zero_acc(acc);
         tile_gemm<MLP_IN_PAD, 2>(P + MLP_OFF_W1, wave * 64, ldsB, acc, lane);
-        epilogue_elu<MLP_H1, 2>(acc, P + MLP_OFF_B1, wave * 64, ldsA, h1_save, row0, n, lane);
+        epilogue_elu<MLP_H1, 2>(acc, P + MLP_OFF_B1, wave * 64, ldsA, lane);
     }
     __syncthreads();
+    copy_tile_out<MLP_H1>(ldsA, h1_save, row0, n, tid);
     {   // L2: 256 -> 128, wave owns 32 columns
         f32x16 acc[1];
         zero_acc(acc);
         tile_gemm<MLP_H1, 1>(P + MLP_OFF_W2, wave * 32, ldsA, acc, lane);
-        epilogue_elu<MLP_H2, 1>(acc, P + MLP_OFF_B2, wave * 32, ldsB, h2_save, row0, n, lane);
+        epilogue_elu<MLP_H2, 1>(acc, P + MLP_OFF_B2, wave * 32, ldsB, lane);
     }
     __syncthreads();
+    copy_tile_out<MLP_H2>(ldsB, h2_save, row0, n, tid);
     {   // L3: 128 -> 128 (actor | critic heads stacked)
         f32x16 acc[1];
         zero_acc(acc);
         tile_gemm<MLP_H2, 1>(P + MLP_OFF_W3, wave * 32, ldsB, acc, lane);
-        epilogue_elu<MLP_H3, 1>(acc, P + MLP_OFF_B3, wave * 32, ldsA, h3_save, row0, n, lane);
+        epilogue_elu<MLP_H3, 1>(acc, P + MLP_OFF_B3, wave * 32, ldsA, lane);
     }
     __syncthreads();
+    copy_tile_out<MLP_H3>(ldsA, h3_save, row0, n, tid);
     {   // L4: 128 -> 32, split-K over the four waves (32 k each), partials reduced through LDS
         f32x16 acc;
 #pragma unroll
@@ -199,19 +214,49 @@ __global__ __launch_bounds__(THREADS) void mlp_forward_kernel(
 //   dz4 [n][32]: cols 0..17 d/d(pre-ELU mean), col 18 d/d(value), rest 0
 //   dz3 [n][128], dz2 [n][128], dz1 [n][256]: gradients at the pre-activations of layers 3,2,1
 //   loss_part [grid][2]: per-workgroup sums of the policy term and of the Huber term
-__device__ __forceinline__ void epilogue_dact(const f32x16& acc, int col, const float* __restrict__ h_saved, int N,
-                                              float* lds_out, float* __restrict__ dz_out, long row0, long nrows, int lane)
+// dZ = dA * ELU'(H), in place on the LDS tile that holds H (pitch N+4): the lane that owns an
+// accumulator element reads H there and overwrites it with dZ.
+__device__ __forceinline__ void epilogue_dact_inplace(const f32x16& acc, int col, int N, float* lds_tile, int lane)
 {
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-        const int row = acc_row(reg, lane);
-        const long grow = row0 + row;
-        const float y = (grow < nrows) ? h_saved[grow * N + col] : 0.0f;
-        const float d = acc[reg] * elu_grad_from_out(y);
-        if (lds_out) lds_out[row * (N + 4) + col] = d;
-        if (grow < nrows) dz_out[grow * N + col] = d;
+        float* p = lds_tile + acc_row(reg, lane) * (N + 4) + col;
+        *p = acc[reg] * elu_grad_from_out(*p);
     }
 }
+
+// global [rows][N] tile (contiguous 32*N floats) -> registers -> LDS tile (pitch N+4), 16-byte moves
+template <int N>
+struct TileRegs { float4 v[(BM * N / 4 + THREADS - 1) / THREADS]; };
+
+template <int N>
+__device__ __forceinline__ void tile_load(TileRegs<N>& t, const float* __restrict__ src, long row0, long nrows, int tid)
+{
+#pragma unroll
+    for (int u = 0; u < (BM * N / 4 + THREADS - 1) / THREADS; ++u) {
+        const int i = tid + u * THREADS;
+        const int row = i / (N / 4), c4 = i - row * (N / 4);
+        t.v[u] = (i < BM * N / 4 && row0 + row < nrows) ? *reinterpret_cast<const float4*>(src + (row0 + row) * N + 4 * c4)
+                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void tile_store_lds(const TileRegs<N>& t, float* lds_tile, int tid)
+{
+#pragma unroll
+    for (int u = 0; u < (BM * N / 4 + THREADS - 1) / THREADS; ++u) {
+        const int i = tid + u * THREADS;
+        const int row = i / (N / 4), c4 = i - row * (N / 4);
+        if (i < BM * N / 4) *reinterpret_cast<float4*>(lds_tile + row * (N + 4) + 4 * c4) = t.v[u];
+    }
+}
+
+constexpr int BW_Z2 = 0;                                   // [32][132]
+constexpr int BW_Z3 = BW_Z2 + BM * (MLP_H2 + 4);           // [32][132]
+constexpr int BW_Z4 = BW_Z3 + BM * (MLP_H3 + 4);           // [32][36]
+constexpr int BW_Z1 = BW_Z3;                               // [32][260] aliases Z3|Z4|tail once they are dead
+constexpr int BW_FLOATS = BW_Z1 + BM * (MLP_H1 + 4) + BM + 8;
 
 __global__ __launch_bounds__(THREADS) void mlp_backward_dx_kernel(
     const float* __restrict__ PT, const float* __restrict__ out_saved, const float* __restrict__ h1_saved,
@@ -221,14 +266,18 @@ __global__ __launch_bounds__(THREADS) void mlp_backward_dx_kernel(
     float* __restrict__ dz4, float* __restrict__ dz3, float* __restrict__ dz2, float* __restrict__ dz1,
     float* __restrict__ loss_part)
 {
-    __shared__ __attribute__((aligned(16))) float lds[BM * (MLP_OUT + 4) + 2 * BM * (MLP_H3 + 4) + BM + 8];
-    float* ldsZ4 = lds;                                   // [32][36]
-    float* ldsZ3 = lds + BM * (MLP_OUT + 4);              // [32][132]
-    float* ldsZ2 = ldsZ3 + BM * (MLP_H3 + 4);             // [32][132]
-    float* coef = ldsZ2 + BM * (MLP_H2 + 4);              // [32] per-row d loss / d logp
+    __shared__ __attribute__((aligned(16))) float lds[BW_FLOATS];
+    float* ldsZ2 = lds + BW_Z2;
+    float* ldsZ3 = lds + BW_Z3;
+    float* ldsZ4 = lds + BW_Z4;
+    float* ldsZ1 = lds + BW_Z1;
+    float* coef = lds + BW_Z1 + BM * (MLP_H1 + 4);        // [32] per-row d loss / d logp
     float* red = coef + BM;                               // [8] loss partials
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long row0 = (long)blockIdx.x * BM;
+
+    TileRegs<MLP_H3> h3r;
+    tile_load<MLP_H3>(h3r, h3_saved, row0, n, tid);       // in flight during the loss phase
 
     // per-row loss terms (one lane per row)
     if (tid < BM) {
@@ -260,10 +309,10 @@ __global__ __launch_bounds__(THREADS) void mlp_backward_dx_kernel(
             hub = fabsf(d) < 1.0f ? 0.5f * d * d : fabsf(d) - 0.5f;
         }
         coef[tid] = c;
-        // wave 0 holds rows 0..31 in lanes 0..31: reduce the two loss sums in-wave
         for (int o = 16; o > 0; o >>= 1) { pol += __shfl_down(pol, o, 32); hub += __shfl_down(hub, o, 32); }
         if (tid == 0) { red[0] = pol; red[1] = hub; }
     }
+    tile_store_lds<MLP_H3>(h3r, ldsZ3, tid);
     __syncthreads();
     if (tid == 0 && loss_part) { loss_part[2 * blockIdx.x] = red[0]; loss_part[2 * blockIdx.x + 1] = red[1]; }
     // dz4 tile
@@ -283,28 +332,39 @@ __global__ __launch_bounds__(THREADS) void mlp_backward_dx_kernel(
         }
         ldsZ4[row * (MLP_OUT + 4) + col] = d;
     }
+    TileRegs<MLP_H2> h2r;
+    tile_load<MLP_H2>(h2r, h2_saved, row0, n, tid);
     __syncthreads();
-    {   // dA3 = dZ4 . W4  ->  dZ3
+    {   // dA3 = dZ4 . W4  ->  dZ3 (in place over the staged H3 tile)
         f32x16 acc[1];
         zero_acc(acc);
         tile_gemm<MLP_OUT, 1>(PT + MLP_OFF_WT4, wave * 32, ldsZ4, acc, lane);
-        epilogue_dact(acc[0], wave * 32 + (lane & 31), h3_saved, MLP_H3, ldsZ3, dz3, row0, n, lane);
+        epilogue_dact_inplace(acc[0], wave * 32 + (lane & 31), MLP_H3, ldsZ3, lane);
     }
+    tile_store_lds<MLP_H2>(h2r, ldsZ2, tid);
     __syncthreads();
+    copy_tile_out<MLP_H3>(ldsZ3, dz3, row0, n, tid);
     {   // dA2 = dZ3 . W3  ->  dZ2
         f32x16 acc[1];
         zero_acc(acc);
         tile_gemm<MLP_H3, 1>(PT + MLP_OFF_WT3, wave * 32, ldsZ3, acc, lane);
-        epilogue_dact(acc[0], wave * 32 + (lane & 31), h2_saved, MLP_H2, ldsZ2, dz2, row0, n, lane);
+        epilogue_dact_inplace(acc[0], wave * 32 + (lane & 31), MLP_H2, ldsZ2, lane);
     }
-    __syncthreads();
+    __syncthreads();                                       // Z3 / Z4 are dead from here: Z1 may overwrite them
+    copy_tile_out<MLP_H2>(ldsZ2, dz2, row0, n, tid);
     {   // dA1 = dZ2 . W2  ->  dZ1
+        TileRegs<MLP_H1> h1r;
+        tile_load<MLP_H1>(h1r, h1_saved, row0, n, tid);    // in flight during the MFMAs
         f32x16 acc[2];
         zero_acc(acc);
         tile_gemm<MLP_H2, 2>(PT + MLP_OFF_WT2, wave * 64, ldsZ2, acc, lane);
-        epilogue_dact(acc[0], wave * 64 + (lane & 31), h1_saved, MLP_H1, nullptr, dz1, row0, n, lane);
-        epilogue_dact(acc[1], wave * 64 + 32 + (lane & 31), h1_saved, MLP_H1, nullptr, dz1, row0, n, lane);
+        tile_store_lds<MLP_H1>(h1r, ldsZ1, tid);
+        __syncthreads();
+        epilogue_dact_inplace(acc[0], wave * 64 + (lane & 31), MLP_H1, ldsZ1, lane);
+        epilogue_dact_inplace(acc[1], wave * 64 + 32 + (lane & 31), MLP_H1, ldsZ1, lane);
     }
+    __syncthreads();
+    copy_tile_out<MLP_H1>(ldsZ1, dz1, row0, n, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -323,88 +383,174 @@ struct GradWLayer {
 };
 struct GradWTable { GradWLayer l[4]; };
 
-constexpr int GW_ROWS = 32;      // rows staged per chunk
+constexpr int GW_ROWS = 32;      // rows staged per chunk (16 MFMA k-steps)
+constexpr int GW_THREADS = 512;  // 8 waves
 
-template <int N, int KP>
+// One layer's slab.  Waves form a WN x WK grid over the (N/32) x (KPAD/32) output tiles; each wave
+// owns TNW x TKW tiles so one pair of operand reads feeds TNW*TKW MFMAs.  Chunks of 32 rows are
+// double-buffered in LDS: the global loads of chunk c+1 are issued (16-byte, coalesced: a chunk is
+// one contiguous block of 32*N floats) before the MFMAs of chunk c and written to the other buffer
+// afterwards, one barrier per chunk.
+template <int N, int KA, int KPAD, int KOUT, int WN, int WK, int TNW, int TKW>
 __device__ void grad_w_layer(const GradWLayer& L, long nrows, int wg, float* lds)
 {
-    // 8 waves; output tiles (N/32) x (KP/32... KP may be 80 -> 3 tiles, last partial)
-    constexpr int TN = N / 32;
-    constexpr int TK = (KP + 31) / 32;
-    constexpr int TILES = TN * TK;
-    constexpr int WAVES = 8;
-    constexpr int PER = (TILES + WAVES - 1) / WAVES;
-    float* ldsZ = lds;                       // [32][N]
-    float* ldsA = lds + GW_ROWS * N;         // [32][TK*32]
+    static_assert(WN * TNW * 32 == N && WK * TKW * 32 == KPAD, "tile grid must cover the output");
+    constexpr bool A_VEC = (KA % 4 == 0);
+    constexpr int ZV = (GW_ROWS * N / 4 + GW_THREADS - 1) / GW_THREADS;          // float4 per thread
+    constexpr int AV = A_VEC ? (GW_ROWS * KA / 4 + GW_THREADS - 1) / GW_THREADS
+                             : (GW_ROWS * KA + GW_THREADS - 1) / GW_THREADS;     // float4 or float per thread
+    constexpr int BUF = GW_ROWS * (N + KPAD);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
+    const bool active = wave < WN * WK;
+    const int wn = active ? wave / WK : 0, wk = active ? wave % WK : 0;
     const long rows_per = (nrows + L.wgs - 1) / L.wgs;
     const long rbeg = (long)wg * rows_per;
     const long rend = (rbeg + rows_per < nrows) ? rbeg + rows_per : nrows;
-    f32x16 acc[PER];
+    const float* __restrict__ gz = L.dz;
+    const float* __restrict__ ga = L.a;
+
+    f32x16 acc[TNW][TKW];
 #pragma unroll
-    for (int t = 0; t < PER; ++t)
+    for (int a = 0; a < TNW; ++a)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-    float bsum = 0.0f;                        // thread tid < N: column sum of dZ
+        for (int b = 0; b < TKW; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+    float bsum = 0.0f;
+
+    float4 zreg[ZV];
+    float4 areg4[A_VEC ? AV : 1];
+    float areg1[A_VEC ? 1 : AV];
+
+    auto load_chunk = [&](long c0) {
+#pragma unroll
+        for (int v = 0; v < ZV; ++v) {
+            const int i = tid + v * GW_THREADS;                 // float4 index inside the chunk
+            const long g = c0 + (i * 4) / N;
+            zreg[v] = (i < GW_ROWS * N / 4 && g < rend) ? *reinterpret_cast<const float4*>(gz + c0 * N + 4L * i)
+                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (A_VEC) {
+#pragma unroll
+            for (int v = 0; v < AV; ++v) {
+                const int i = tid + v * GW_THREADS;
+                const long g = c0 + (i * 4) / KA;
+                areg4[v] = (i < GW_ROWS * KA / 4 && g < rend) ? *reinterpret_cast<const float4*>(ga + c0 * KA + 4L * i)
+                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < AV; ++v) {
+                const int i = tid + v * GW_THREADS;
+                const long g = c0 + i / KA;
+                areg1[v] = (i < GW_ROWS * KA && g < rend) ? ga[c0 * KA + i] : 0.0f;
+            }
+        }
+    };
+    auto store_chunk = [&](float* buf) {
+        float* bz = buf;
+        float* ba = buf + GW_ROWS * N;
+#pragma unroll
+        for (int v = 0; v < ZV; ++v) {
+            const int i = tid + v * GW_THREADS;
+            if (i < GW_ROWS * N / 4) *reinterpret_cast<float4*>(bz + 4 * i) = zreg[v];
+        }
+        if (A_VEC) {
+#pragma unroll
+            for (int v = 0; v < AV; ++v) {
+                const int i = tid + v * GW_THREADS;
+                if (i < GW_ROWS * KA / 4) {
+                    const int rr = (4 * i) / KA, cc = (4 * i) - rr * KA;
+                    *reinterpret_cast<float4*>(ba + rr * KPAD + cc) = areg4[v];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < AV; ++v) {
+                const int i = tid + v * GW_THREADS;
+                if (i < GW_ROWS * KA) {
+                    const int rr = i / KA, cc = i - rr * KA;
+                    ba[rr * KPAD + cc] = areg1[v];
+                }
+            }
+        }
+    };
+
+    // zero the A padding columns once (KA < KPAD only for the input layer)
+    if (KA < KPAD) {
+        for (int i = tid; i < 2 * BUF; i += GW_THREADS) lds[i] = 0.0f;
+        __syncthreads();
+    }
+    load_chunk(rbeg);
+    store_chunk(lds);
+    __syncthreads();
+    int cur = 0;
     for (long c0 = rbeg; c0 < rend; c0 += GW_ROWS) {
-        __syncthreads();
-        for (int i = tid; i < GW_ROWS * N; i += 512) {
-            const int rr = i / N, cc = i - rr * N;
-            const long g = c0 + rr;
-            ldsZ[i] = (g < rend) ? L.dz[g * N + cc] : 0.0f;
-        }
-        for (int i = tid; i < GW_ROWS * TK * 32; i += 512) {
-            const int rr = i / (TK * 32), cc = i - rr * (TK * 32);
-            const long g = c0 + rr;
-            ldsA[i] = (g < rend && cc < L.Ka) ? L.a[g * L.Ka + cc] : 0.0f;
-        }
-        __syncthreads();
+        const bool more = c0 + GW_ROWS < rend;
+        if (more) load_chunk(c0 + GW_ROWS);                     // in flight during the MFMAs below
+        const float* bz = lds + cur * BUF;
+        const float* ba = bz + GW_ROWS * N;
         if (tid < N) {
 #pragma unroll 8
-            for (int rr = 0; rr < GW_ROWS; ++rr) bsum += ldsZ[rr * N + tid];
+            for (int rr = 0; rr < GW_ROWS; ++rr) bsum += bz[rr * N + tid];
         }
+        if (active) {
+            const float* zp = bz + h * N + wn * (TNW * 32) + r;
+            const float* ap = ba + h * KPAD + wk * (TKW * 32) + r;
+#pragma unroll 4
+            for (int st = 0; st < GW_ROWS / 2; ++st) {
+                float zv[TNW], av[TKW];
 #pragma unroll
-        for (int t = 0; t < PER; ++t) {
-            const int tile = wave + WAVES * t;
-            if (tile < TILES) {
-                const int tn = tile / TK, tk = tile - tn * TK;
-                const float* zp = ldsZ + h * N + tn * 32 + r;
-                const float* ap = ldsA + h * (TK * 32) + tk * 32 + r;
-#pragma unroll 8
-                for (int s = 0; s < GW_ROWS / 2; ++s)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(zp[2 * s * N], ap[2 * s * (TK * 32)], acc[t], 0, 0, 0);
+                for (int a = 0; a < TNW; ++a) zv[a] = zp[2 * st * N + 32 * a];
+#pragma unroll
+                for (int b = 0; b < TKW; ++b) av[b] = ap[2 * st * KPAD + 32 * b];
+#pragma unroll
+                for (int a = 0; a < TNW; ++a)
+#pragma unroll
+                    for (int b = 0; b < TKW; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(zv[a], av[b], acc[a][b], 0, 0, 0);
             }
         }
+        if (more) store_chunk(lds + (cur ^ 1) * BUF);
+        __syncthreads();
+        cur ^= 1;
     }
-    float* out = L.partial + (long)wg * N * (KP + 1);
+    float* out = L.partial + (long)wg * N * (KOUT + 1);
+    if (active) {
 #pragma unroll
-    for (int t = 0; t < PER; ++t) {
-        const int tile = wave + WAVES * t;
-        if (tile < TILES) {
-            const int tn = tile / TK, tk = tile - tn * TK;
-            const int col = tk * 32 + r;                       // k index
+        for (int a = 0; a < TNW; ++a)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int row = tn * 32 + acc_row(reg, lane);  // n index
-                if (col < KP) out[row * (KP + 1) + col] = acc[t][reg];
+            for (int b = 0; b < TKW; ++b) {
+                const int col = wk * (TKW * 32) + 32 * b + r;                   // k index
+                if (col < KOUT) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int row = wn * (TNW * 32) + 32 * a + acc_row(reg, lane);   // n index
+                        out[row * (KOUT + 1) + col] = acc[a][b][reg];
+                    }
+                }
             }
-        }
     }
-    if (tid < N) out[tid * (KP + 1) + KP] = bsum;
+    if (tid < N) out[tid * (KOUT + 1) + KOUT] = bsum;
 }
 
-__global__ __launch_bounds__(512) void mlp_grad_w_kernel(GradWTable T, long nrows)
+__global__ __launch_bounds__(GW_THREADS) void mlp_grad_w_kernel(GradWTable T, long nrows)
 {
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     const int b = blockIdx.x;
-    if (b >= T.l[3].first_block) grad_w_layer<MLP_OUT, MLP_H3>(T.l[3], nrows, b - T.l[3].first_block, lds_dyn);
-    else if (b >= T.l[2].first_block) grad_w_layer<MLP_H3, MLP_H2>(T.l[2], nrows, b - T.l[2].first_block, lds_dyn);
-    else if (b >= T.l[1].first_block) grad_w_layer<MLP_H2, MLP_H1>(T.l[1], nrows, b - T.l[1].first_block, lds_dyn);
-    else grad_w_layer<MLP_H1, MLP_IN_PAD>(T.l[0], nrows, b, lds_dyn);
+    if (b >= T.l[3].first_block)
+        grad_w_layer<MLP_OUT, MLP_H3, MLP_H3, MLP_H3, 1, 4, 1, 1>(T.l[3], nrows, b - T.l[3].first_block, lds_dyn);
+    else if (b >= T.l[2].first_block)
+        grad_w_layer<MLP_H3, MLP_H2, MLP_H2, MLP_H2, 4, 2, 1, 2>(T.l[2], nrows, b - T.l[2].first_block, lds_dyn);
+    else if (b >= T.l[1].first_block)
+        grad_w_layer<MLP_H2, MLP_H1, MLP_H1, MLP_H1, 2, 4, 2, 2>(T.l[1], nrows, b - T.l[1].first_block, lds_dyn);
+    else
+        grad_w_layer<MLP_H1, MLP_IN, 96, MLP_IN_PAD, 8, 1, 1, 3>(T.l[0], nrows, b, lds_dyn);
 }
 
-// sum the per-workgroup partials into the packed gradient buffer (layout of P); fixed order.
+// sum the per-workgroup partials into the packed gradient buffer (layout of P); fixed order, eight
+// independent partial sums per thread so that eight loads are in flight.
 __global__ __launch_bounds__(256) void mlp_grad_reduce_kernel(GradWTable T, float* __restrict__ G)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -414,81 +560,97 @@ __global__ __launch_bounds__(256) void mlp_grad_reduce_kernel(GradWTable T, floa
     else if (i < MLP_OFF_W3) { layer = 1; off_w = MLP_OFF_W2; off_b = MLP_OFF_B2; N = MLP_H2; KP = MLP_H1; }
     else if (i < MLP_OFF_W4) { layer = 2; off_w = MLP_OFF_W3; off_b = MLP_OFF_B3; N = MLP_H3; KP = MLP_H2; }
     else { layer = 3; off_w = MLP_OFF_W4; off_b = MLP_OFF_B4; N = MLP_OUT; KP = MLP_H3; }
-    const GradWLayer& L = T.l[layer];
+    const float* part = layer == 0 ? T.l[0].partial : layer == 1 ? T.l[1].partial : layer == 2 ? T.l[2].partial : T.l[3].partial;
+    const int wgs = layer == 0 ? T.l[0].wgs : layer == 1 ? T.l[1].wgs : layer == 2 ? T.l[2].wgs : T.l[3].wgs;
     long idx;
     if (i < off_b) { const int rr = (i - off_w) / KP, cc = (i - off_w) - rr * KP; idx = (long)rr * (KP + 1) + cc; }
     else idx = (long)(i - off_b) * (KP + 1) + KP;
     const long stride = (long)N * (KP + 1);
-    float s = 0.0f;
-    for (int w = 0; w < L.wgs; ++w) s += L.partial[w * stride + idx];
-    G[i] = s;
+    float s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int w = 0;
+    for (; w + 8 <= wgs; w += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s8[u] += part[(w + u) * stride + idx];
+    }
+    for (; w < wgs; ++w) s8[w & 7] += part[w * stride + idx];
+    G[i] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // Optimizer step (ppo.py:196-199): clip_grad_norm_(max_norm) + Adam (torch defaults: no weight
-// decay, no amsgrad) over the packed parameter buffer, plus the refresh of the transposed
-// weights the next backward pass streams.  ONE workgroup of 1024 threads: 74 272 elements are
-// 73 per thread, the global-norm reduction stays inside the workgroup (fixed order, so the
-// step is deterministic), and nothing needs a second launch or a host round trip.  The step
-// counter lives in device memory so the launch is graph-capturable.
-__global__ __launch_bounds__(1024) void mlp_adam_kernel(float* __restrict__ P, float* __restrict__ PT,
-                                                        const float* __restrict__ G, const float* __restrict__ mask,
-                                                        float* __restrict__ m, float* __restrict__ v,
-                                                        int* __restrict__ step, float lr, float beta1, float beta2,
-                                                        float eps, float max_norm, float grad_scale,
-                                                        float* __restrict__ norm_out)
+// decay, no amsgrad) over the packed parameter buffer, plus the refresh of the transposed weights
+// the next backward pass streams.  Two small launches: per-block sums of squares of the masked,
+// scaled gradient (fixed order: deterministic), then the update, where every block re-adds the
+// 73 block sums in the same order and so derives the same clip coefficient.  The step counter
+// lives in device memory (incremented by the first launch), so both are graph-capturable.
+constexpr int ADAM_THREADS = 1024;
+constexpr int ADAM_BLOCKS = (MLP_PACKED_FLOATS + ADAM_THREADS - 1) / ADAM_THREADS;   // 73
+
+__global__ __launch_bounds__(ADAM_THREADS) void mlp_adam_norm_kernel(const float* __restrict__ G,
+                                                                     const float* __restrict__ mask, float grad_scale,
+                                                                     float* __restrict__ norm_ws, int* __restrict__ step)
 {
     __shared__ float red[16];
-    __shared__ float s_coef;
     const int tid = threadIdx.x;
+    const int i = blockIdx.x * ADAM_THREADS + tid;
     float ss = 0.0f;
-    for (int i = tid; i < MLP_PACKED_FLOATS; i += 1024) {
-        const float g = G[i] * grad_scale * mask[i];
-        ss += g * g;
-    }
+    if (i < MLP_PACKED_FLOATS) { const float g = G[i] * grad_scale * mask[i]; ss = g * g; }
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
     if ((tid & 63) == 0) red[tid >> 6] = ss;
     __syncthreads();
     if (tid == 0) {
         float t = 0.0f;
         for (int w = 0; w < 16; ++w) t += red[w];
+        norm_ws[1 + blockIdx.x] = t;
+        if (blockIdx.x == 0) *step += 1;
+    }
+}
+
+__global__ __launch_bounds__(ADAM_THREADS) void mlp_adam_apply_kernel(float* __restrict__ P, float* __restrict__ PT,
+                                                                      const float* __restrict__ G,
+                                                                      const float* __restrict__ mask,
+                                                                      float* __restrict__ m, float* __restrict__ v,
+                                                                      const int* __restrict__ step, float lr, float beta1,
+                                                                      float beta2, float eps, float max_norm,
+                                                                      float grad_scale, float* __restrict__ norm_ws)
+{
+    __shared__ float s_coef;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        float t = 0.0f;
+        for (int b = 0; b < ADAM_BLOCKS; ++b) t += norm_ws[1 + b];
         const float norm = sqrtf(t);
-        float coef = max_norm / (norm + 1e-6f);            // torch.nn.utils.clip_grad_norm_
+        const float coef = max_norm / (norm + 1e-6f);          // torch.nn.utils.clip_grad_norm_
         s_coef = coef < 1.0f ? coef : 1.0f;
-        if (norm_out) *norm_out = norm;
-        *step += 1;
+        if (blockIdx.x == 0) norm_ws[0] = norm;
     }
     __syncthreads();
+    const int i = blockIdx.x * ADAM_THREADS + tid;
+    if (i >= MLP_PACKED_FLOATS) return;
     const float coef = s_coef * grad_scale;
     const int t = *step;
     const float bc1 = 1.0f - powf(beta1, (float)t);
     const float bc2 = 1.0f - powf(beta2, (float)t);
     const float step_size = lr / bc1;
     const float bc2_sqrt = sqrtf(bc2);
-    for (int i = tid; i < MLP_PACKED_FLOATS; i += 1024) {
-        const float mk = mask[i];
-        const float g = G[i] * coef * mk;
-        const float mi = beta1 * m[i] + (1.0f - beta1) * g;
-        const float vi = beta2 * v[i] + (1.0f - beta2) * g * g;
-        m[i] = mi; v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        P[i] = P[i] - mk * (step_size * (mi / denom));
-    }
-    __syncthreads();
-    __threadfence_block();
-    // transposes for the dX chain
-    for (int i = tid; i < MLP_H2 * MLP_H1; i += 1024) {            // W2 [128][256] -> Wt2 [256][128]
-        const int nn = i / MLP_H1, kk = i - nn * MLP_H1;
-        PT[MLP_OFF_WT2 + kk * MLP_H2 + nn] = P[MLP_OFF_W2 + i];
-    }
-    for (int i = tid; i < MLP_H3 * MLP_H2; i += 1024) {            // W3 [128][128] -> Wt3
-        const int nn = i / MLP_H2, kk = i - nn * MLP_H2;
-        PT[MLP_OFF_WT3 + kk * MLP_H3 + nn] = P[MLP_OFF_W3 + i];
-    }
-    for (int i = tid; i < MLP_OUT * MLP_H3; i += 1024) {           // W4 [32][128] -> Wt4 [128][32]
-        const int nn = i / MLP_H3, kk = i - nn * MLP_H3;
-        PT[MLP_OFF_WT4 + kk * MLP_OUT + nn] = P[MLP_OFF_W4 + i];
+    const float mk = mask[i];
+    const float g = G[i] * coef * mk;
+    const float mi = beta1 * m[i] + (1.0f - beta1) * g;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * g * g;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    const float p = P[i] - mk * (step_size * (mi / denom));
+    P[i] = p;
+    // transposes for the dX chain (each weight element also lands in PT)
+    if (i >= MLP_OFF_W2 && i < MLP_OFF_B2) {
+        const int j = i - MLP_OFF_W2, nn = j / MLP_H1, kk = j - nn * MLP_H1;
+        PT[MLP_OFF_WT2 + kk * MLP_H2 + nn] = p;
+    } else if (i >= MLP_OFF_W3 && i < MLP_OFF_B3) {
+        const int j = i - MLP_OFF_W3, nn = j / MLP_H2, kk = j - nn * MLP_H2;
+        PT[MLP_OFF_WT3 + kk * MLP_H3 + nn] = p;
+    } else if (i >= MLP_OFF_W4 && i < MLP_OFF_B4) {
+        const int j = i - MLP_OFF_W4, nn = j / MLP_H3, kk = j - nn * MLP_H3;
+        PT[MLP_OFF_WT4 + kk * MLP_OUT + nn] = p;
     }
 }
 
@@ -546,9 +708,17 @@ extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, 
         first += kGradWgs[l];
     }
     // dynamic LDS: the largest layer's staging tiles: max over layers of 32*(N + TK*32) floats
-    const size_t lds_bytes = sizeof(float) * GW_ROWS * (MLP_H2 + MLP_H1);     // layer 2: 32 x (128 + 256)
-    static_assert(GW_ROWS * (MLP_H1 + 96) <= GW_ROWS * (MLP_H2 + MLP_H1), "layer 1 tiles fit");
-    hipLaunchKernelGGL(mlp_grad_w_kernel, dim3(first), dim3(512), lds_bytes, (hipStream_t)stream, T, (long)n);
+    // dynamic LDS: two buffers of the largest layer's chunk: 2 x 32 x (128 + 256) floats = 96 KiB
+    const size_t lds_bytes = sizeof(float) * 2 * GW_ROWS * (MLP_H2 + MLP_H1);
+    static_assert(MLP_H1 + 96 <= MLP_H2 + MLP_H1, "layer 1 chunk fits");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_grad_w_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (ea != hipSuccess) return ea;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(mlp_grad_w_kernel, dim3(first), dim3(GW_THREADS), lds_bytes, (hipStream_t)stream, T, (long)n);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((MLP_PACKED_FLOATS + 255) / 256), dim3(256), 0,
@@ -558,9 +728,13 @@ extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, 
 
 extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PT, const float* G, const float* mask, float* m,
                                              float* v, int* step, float lr, float beta1, float beta2, float eps,
-                                             float max_norm, float grad_scale, float* norm_out, void* stream)
+                                             float max_norm, float grad_scale, float* norm_ws, void* stream)
 {
-    hipLaunchKernelGGL(mlp_adam_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, P, PT, G, mask, m, v, step,
-                       lr, beta1, beta2, eps, max_norm, grad_scale, norm_out);
+    hipLaunchKernelGGL(mlp_adam_norm_kernel, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, G, mask,
+                       grad_scale, norm_ws, step);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(mlp_adam_apply_kernel, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, P, PT, G,
+                       mask, m, v, step, lr, beta1, beta2, eps, max_norm, grad_scale, norm_ws);
     return hipGetLastError();
 }

@@ -96,7 +96,8 @@ class PackedPolicy:
         self.exp_avg = torch.zeros(PACKED, device=dev)
         self.exp_avg_sq = torch.zeros(PACKED, device=dev)
         self.step = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.grad_norm = torch.zeros(1, device=dev)
+        self._norm_ws = torch.zeros(128, device=dev)       # [0] = pre-clip gradient norm, rest scratch
+        self.grad_norm = self._norm_ws[:1]
         self.workspace = torch.empty(int(self._lib.mlp_grad_workspace_floats()), device=dev)
         self.max_rows = int(max_rows)
         r = self.max_rows
@@ -136,5 +137,5 @@ class PackedPolicy:
         _lib.check(self._lib.mlp_adam_step(p(self.P), p(self.PT), p(self.G), p(self.grad_mask), p(self.exp_avg),
                                            p(self.exp_avg_sq), p(self.step), C.c_float(self.lr),
                                            C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
-                                           C.c_float(self.max_norm), C.c_float(grad_scale), p(self.grad_norm),
+                                           C.c_float(self.max_norm), C.c_float(grad_scale), p(self._norm_ws),
                                            _lib.stream_ptr()), "mlp_adam_step")

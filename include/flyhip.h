@@ -196,7 +196,9 @@ int mlp_forward(const float* params, const float* x, int64_t n, float* mu_out, f
  *                     mlp_grad_workspace_floats() floats.
  *   mlp_adam_step   : grad *= grad_scale; clip_grad_norm_(max_norm); Adam with torch defaults;
  *                     refreshes params_t (the transposed weights).  `mask` (packed layout, 0/1)
- *                     freezes padding and structural zeros.  `step` is a device int counter.
+ *                     freezes padding and structural zeros.  `step` is a device int counter;
+ *                     `norm_ws` is a device scratch of >= 128 floats, norm_ws[0] returns the
+ *                     pre-clip gradient norm.
  */
 int64_t mlp_grad_workspace_floats(void);
 int mlp_backward_dx(const float* params_t, const float* out_saved, const float* h1_saved,
@@ -209,7 +211,7 @@ int mlp_grad_w(const float* x, const float* h1_saved, const float* h2_saved, con
                float* workspace, float* grad, void* stream);
 int mlp_adam_step(float* params, float* params_t, const float* grad, const float* mask, float* exp_avg,
                   float* exp_avg_sq, int32_t* step, float lr, float beta1, float beta2, float eps,
-                  float max_norm, float grad_scale, float* norm_out, void* stream);
+                  float max_norm, float grad_scale, float* norm_ws, void* stream);
 
 #ifdef __cplusplus
 }
