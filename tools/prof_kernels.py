@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Launch each hot kernel a fixed number of times at the bench sizes (for rocprofv3 kernel-trace /
+PMC passes).  Usage on the GPU box:
+    rocprofv3 --kernel-trace --stats --output-format csv -d OUT -- python3 tools/prof_kernels.py
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d OUT -- python3 tools/prof_kernels.py
+"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from bench import make_args  # noqa: E402
+from fly_bproject_amd import _lib  # noqa: E402
+from fly_bproject_amd.fly import Fly  # noqa: E402
+from fly_bproject_amd.policy import PackedPolicy  # noqa: E402
+from fly_bproject_amd.ppo import Net  # noqa: E402
+
+REPS = int(os.environ.get("PROF_REPS", "20"))
+N = int(os.environ.get("PROF_ENVS", "8192"))
+lib = _lib.load()
+env = Fly(make_args(N))
+a = torch.zeros(N, 18, device="cuda:0").uniform_(-1, 1)
+for _ in range(REPS):
+    env.step(a)
+rows = (40960 // N) * N
+net = Net(73, 18).to("cuda:0")
+pol = PackedPolicy(net, "cuda:0")
+pol.init_training(rows)
+x = torch.randn(rows, 73, device="cuda:0")
+act = torch.rand(rows, 18, device="cuda:0") * 2 - 1
+olp = torch.randn(rows, device="cuda:0") - 20
+adv = torch.randn(rows, device="cuda:0")
+tgt = torch.randn(rows, device="cuda:0")
+var = torch.full((18,), 0.2, device="cuda:0")
+for _ in range(REPS):
+    pol.minibatch_grad(x, act, olp, adv, tgt, var, 0.2)
+    pol.adam_step()
+xs = torch.randn(N, 73, device="cuda:0")
+with torch.no_grad():
+    for _ in range(REPS):
+        pol.forward(xs, want_mu=True, want_v=False)
+torch.cuda.synchronize()
+env.exit()
+print("done")
