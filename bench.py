@@ -96,7 +96,7 @@ def kernel_rooflines(num_envs, T, reps):
     p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
     s, d = pol.saves, pol.dz
     pol.minibatch_grad(x, act, olp, adv, tgt, var, 0.2)
-    t_fwd = _time_launches(lambda: lib.mlp_forward(p(pol.P), p(x), rows, None, None, p(s["out"]), p(s["h1"]),
+    t_fwd = _time_launches(lambda: lib.mlp_forward(p(pol.P), p(pol.PF), p(x), rows, None, None, p(s["out"]), p(s["h1"]),
                                                     p(s["h2"]), p(s["h3"]), _lib.stream_ptr()), reps)
     t_bwd = _time_launches(lambda: lib.mlp_backward_dx(p(pol.PT), p(s["out"]), p(s["h1"]), p(s["h2"]), p(s["h3"]),
                                                        p(act), p(olp), p(adv), p(tgt), p(var), rows, 1.0 / rows, 0.2,

@@ -16,7 +16,7 @@ extern "C" hipError_t flyhip_launch_td_gae(const float* reward, const float* v, 
                                            const float* done, float gamma, float lambda, int64_t T, int64_t N,
                                            float* target_out, float* adv_out, int mode, void* stream);
 
-extern "C" hipError_t flyhip_launch_mlp_forward(const float* P, const float* x, int64_t n, float* mu_out,
+extern "C" hipError_t flyhip_launch_mlp_forward(const float* P, const float* PF, const float* x, int64_t n, float* mu_out,
                                                 float* v_out, float* out_save, float* h1_save, float* h2_save,
                                                 float* h3_save, void* stream);
 
@@ -30,7 +30,8 @@ extern "C" int64_t flyhip_mlp_grad_workspace_floats(void);
 extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, const float* h2, const float* h3,
                                                const float* dz1, const float* dz2, const float* dz3, const float* dz4,
                                                int64_t n, float* workspace, float* grad_out, void* stream);
-extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PT, const float* G, const float* mask, float* m,
+extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PF, float* PT, const int* idx_f, const int* idx_t,
+                                             const float* G, const float* mask, float* m,
                                              float* v, int* step, float lr, float beta1, float beta2, float eps,
                                              float max_norm, float grad_scale, float* norm_ws, void* stream);
 
@@ -185,13 +186,13 @@ int ppo_step_bookkeeping(const float* reward, int64_t n, float* score_acc, float
     return FLY_OK;
 }
 
-int mlp_forward(const float* params, const float* x, int64_t n, float* mu_out, float* v_out,
+int mlp_forward(const float* params, const float* params_frag, const float* x, int64_t n, float* mu_out, float* v_out,
                 float* out_save, float* h1_save, float* h2_save, float* h3_save, void* stream)
 {
-    if (!params || !x) return fail(FLY_E_ARG, "mlp_forward: null params/x");
+    if (!params || !params_frag || !x) return fail(FLY_E_ARG, "mlp_forward: null params/x");
     if (n <= 0) return fail(FLY_E_ARG, "mlp_forward: n must be > 0");
-    if (((uintptr_t)params & 15)) return fail(FLY_E_ARG, "mlp_forward: params must be 16-byte aligned");
-    hipError_t e = flyhip_launch_mlp_forward(params, x, n, mu_out, v_out, out_save, h1_save, h2_save, h3_save, stream);
+    if (((uintptr_t)params_frag & 15)) return fail(FLY_E_ARG, "mlp_forward: params_frag must be 16-byte aligned");
+    hipError_t e = flyhip_launch_mlp_forward(params, params_frag, x, n, mu_out, v_out, out_save, h1_save, h2_save, h3_save, stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_forward launch");
     return FLY_OK;
 }
@@ -227,13 +228,15 @@ int mlp_grad_w(const float* x, const float* h1_saved, const float* h2_saved, con
     return FLY_OK;
 }
 
-int mlp_adam_step(float* params, float* params_t, const float* grad, const float* mask, float* exp_avg,
+int mlp_adam_step(float* params, float* params_frag, float* params_t_frag, const int32_t* idx_frag,
+                  const int32_t* idx_t_frag, const float* grad, const float* mask, float* exp_avg,
                   float* exp_avg_sq, int32_t* step, float lr, float beta1, float beta2, float eps,
                   float max_norm, float grad_scale, float* norm_ws, void* stream)
 {
-    if (!params || !params_t || !grad || !mask || !exp_avg || !exp_avg_sq || !step || !norm_ws)
+    if (!params || !params_frag || !params_t_frag || !idx_frag || !idx_t_frag || !grad || !mask || !exp_avg ||
+        !exp_avg_sq || !step || !norm_ws)
         return fail(FLY_E_ARG, "mlp_adam_step: null pointer");
-    hipError_t e = flyhip_launch_mlp_adam(params, params_t, grad, mask, exp_avg, exp_avg_sq, step, lr, beta1, beta2,
+    hipError_t e = flyhip_launch_mlp_adam(params, params_frag, params_t_frag, idx_frag, idx_t_frag, grad, mask, exp_avg, exp_avg_sq, step, lr, beta1, beta2,
                                           eps, max_norm, grad_scale, norm_ws, stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_adam_step launch");
     return FLY_OK;

@@ -15,8 +15,19 @@
 //   The torch-visible parameters are strided views into this buffer, so there is one copy of truth.
 //   Structural zeros stay zero because their gradients are masked (policy.py).
 //
-// A second buffer `PT` (MLP_PACKED_T_FLOATS) holds the transposes the backward pass streams:
-//   Wt2 [256][128], Wt3 [128][128], Wt4 [128][32].
+// The kernels do not stream `P` itself: a wave's MFMA B-fragment is (32 output columns) x (4
+// consecutive k) per lane-half, and fetching that from a row-major matrix touches 64 different
+// cache lines per wave-instruction.  Two derived buffers hold the same weights in FRAGMENT ORDER,
+// so that every wave-instruction reads one contiguous 1 KiB block:
+//   PF  (MLP_FRAG_FLOATS)   forward operands  W_l   [N][K]
+//   PTF (MLP_FRAG_T_FLOATS) backward operands W_l^T [K][N]  (layers 2..4; layer 1 needs no dX)
+// Fragment order of a [N][K] operand (N outputs, K reduced): element (n, k) lives at
+//     (((n/32) * (K/8) + kq) * 64 + (h*32 + n%32)) * 4 + q,   h = k / (K/2), kk = k % (K/2),
+//     kq = kk / 4, q = kk % 4
+// i.e. [column tile][k-quad][lane][4].  Layer 4 forward (split-K over the four waves) uses
+//     ((w*4 + kq) * 64 + (h*32 + n)) * 4 + q,   w = k/32, h = (k%32)/16, kq = (k%16)/4, q = k%4.
+// fly_bproject_amd/policy.py builds the index maps; mlp_adam_step scatters every updated weight
+// into PF/PTF, so the three buffers never diverge.
 #ifndef MLP_LAYOUT_H
 #define MLP_LAYOUT_H
 
@@ -38,9 +49,15 @@
 #define MLP_OFF_B4 (MLP_OFF_W4 + MLP_OUT * MLP_H3)         /* 74240 */
 #define MLP_PACKED_FLOATS (MLP_OFF_B4 + MLP_OUT)           /* 74272 */
 
-#define MLP_OFF_WT2 0
-#define MLP_OFF_WT3 (MLP_OFF_WT2 + MLP_H1 * MLP_H2)        /* 32768 */
-#define MLP_OFF_WT4 (MLP_OFF_WT3 + MLP_H2 * MLP_H3)        /* 49152 */
-#define MLP_PACKED_T_FLOATS (MLP_OFF_WT4 + MLP_H3 * MLP_OUT) /* 53248 */
+#define MLP_OFF_F1 0
+#define MLP_OFF_F2 (MLP_OFF_F1 + MLP_H1 * MLP_IN_PAD)      /* 20480 */
+#define MLP_OFF_F3 (MLP_OFF_F2 + MLP_H2 * MLP_H1)          /* 53248 */
+#define MLP_OFF_F4 (MLP_OFF_F3 + MLP_H3 * MLP_H2)          /* 69632 */
+#define MLP_FRAG_FLOATS (MLP_OFF_F4 + MLP_OUT * MLP_H3)    /* 73728 */
+
+#define MLP_OFF_TF2 0                                      /* W2^T: 256 outputs, 128 reduced */
+#define MLP_OFF_TF3 (MLP_OFF_TF2 + MLP_H1 * MLP_H2)        /* 32768: W3^T 128 x 128 */
+#define MLP_OFF_TF4 (MLP_OFF_TF3 + MLP_H2 * MLP_H3)        /* 49152: W4^T 128 outputs, 32 reduced */
+#define MLP_FRAG_T_FLOATS (MLP_OFF_TF4 + MLP_H3 * MLP_OUT) /* 53248 */
 
 #endif

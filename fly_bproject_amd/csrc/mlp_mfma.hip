@@ -39,17 +39,18 @@ __device__ __forceinline__ float elu_grad_from_out(float y) { return y > 0.0f ? 
 
 // acc[t] += A[32 x K] * W[col tile t][K]^T for this wave's NT column tiles.
 //   lds_in : [32][K+4] floats (row-major, k contiguous)
-//   W      : global, row-major [N][K]; `col0` = first output column of this wave
+//   Wf     : this layer's weights in fragment order (mlp_layout.h): [col tile][K/8][64 lanes][4];
+//            `tile0` = first column tile of this wave.  One wave-instruction = one contiguous KiB.
 // k mapping: MFMA step s = 4*kq+q multiplies k = 4*kq+q (lanes 0..31) and k = K/2+4*kq+q (32..63).
 template <int K, int NT>
-__device__ __forceinline__ void tile_gemm(const float* __restrict__ W, int col0, const float* lds_in,
+__device__ __forceinline__ void tile_gemm(const float* __restrict__ Wf, int tile0, const float* lds_in,
                                           f32x16 (&acc)[NT], int lane)
 {
     const int r = lane & 31, h = lane >> 5;
     const float* ap = lds_in + r * (K + 4) + h * (K / 2);
     const float* bp[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) bp[t] = W + (long)(col0 + 32 * t + r) * K + h * (K / 2);
+    for (int t = 0; t < NT; ++t) bp[t] = Wf + (long)(tile0 + t) * (K / 8) * 256 + lane * 4;
     float4 bnext[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) bnext[t] = *reinterpret_cast<const float4*>(bp[t]);
@@ -60,7 +61,7 @@ __device__ __forceinline__ void tile_gemm(const float* __restrict__ W, int col0,
         for (int t = 0; t < NT; ++t) b[t] = bnext[t];
         if (kq + 1 < K / 8) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) bnext[t] = *reinterpret_cast<const float4*>(bp[t] + 4 * (kq + 1));
+            for (int t = 0; t < NT; ++t) bnext[t] = *reinterpret_cast<const float4*>(bp[t] + 256 * (kq + 1));
         }
         const float4 a = *reinterpret_cast<const float4*>(ap + 4 * kq);
 #pragma unroll
@@ -121,7 +122,7 @@ constexpr int LDS_B_FLOATS = BM * (MLP_H2 + 4);      // X0, later H2, later the 
 // x [n][73] -> out [n][32] (cols 0..17 = mean after ELU, col 18 = value, rest 0).
 // mu_out [n][18] / v_out [n] / h*_save are optional.
 __global__ __launch_bounds__(THREADS) void mlp_forward_kernel(
-    const float* __restrict__ P, const float* __restrict__ x, long n,
+    const float* __restrict__ P, const float* __restrict__ PF, const float* __restrict__ x, long n,
     float* __restrict__ mu_out, float* __restrict__ v_out, float* __restrict__ out_save,
     float* __restrict__ h1_save, float* __restrict__ h2_save, float* __restrict__ h3_save)
 {
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(THREADS) void mlp_forward_kernel(
     {   // L1: 80 -> 256, wave owns 64 columns
         f32x16 acc[2];
         zero_acc(acc);
-        tile_gemm<MLP_IN_PAD, 2>(P + MLP_OFF_W1, wave * 64, ldsB, acc, lane);
+        tile_gemm<MLP_IN_PAD, 2>(PF + MLP_OFF_F1, wave * 2, ldsB, acc, lane);
         epilogue_elu<MLP_H1, 2>(acc, P + MLP_OFF_B1, wave * 64, ldsA, lane);
     }
     __syncthreads();
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(THREADS) void mlp_forward_kernel(
     {   // L2: 256 -> 128, wave owns 32 columns
         f32x16 acc[1];
         zero_acc(acc);
-        tile_gemm<MLP_H1, 1>(P + MLP_OFF_W2, wave * 32, ldsA, acc, lane);
+        tile_gemm<MLP_H1, 1>(PF + MLP_OFF_F2, wave, ldsA, acc, lane);
         epilogue_elu<MLP_H2, 1>(acc, P + MLP_OFF_B2, wave * 32, ldsB, lane);
     }
     __syncthreads();
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(THREADS) void mlp_forward_kernel(
     {   // L3: 128 -> 128 (actor | critic heads stacked)
         f32x16 acc[1];
         zero_acc(acc);
-        tile_gemm<MLP_H2, 1>(P + MLP_OFF_W3, wave * 32, ldsB, acc, lane);
+        tile_gemm<MLP_H2, 1>(PF + MLP_OFF_F3, wave, ldsB, acc, lane);
         epilogue_elu<MLP_H3, 1>(acc, P + MLP_OFF_B3, wave * 32, ldsA, lane);
     }
     __syncthreads();
@@ -174,11 +175,11 @@ __global__ __launch_bounds__(THREADS) void mlp_forward_kernel(
         for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
         const int r = lane & 31, h = lane >> 5;
         const float* ap = ldsA + r * (MLP_H3 + 4) + wave * 32 + h * 16;
-        const float* bp = P + MLP_OFF_W4 + (long)r * MLP_H3 + wave * 32 + h * 16;
+        const float* bp = PF + MLP_OFF_F4 + (wave * 4) * 256 + lane * 4;    // [wave][kq][lane][4]
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq) {
             const float4 a = *reinterpret_cast<const float4*>(ap + 4 * kq);
-            const float4 b = *reinterpret_cast<const float4*>(bp + 4 * kq);
+            const float4 b = *reinterpret_cast<const float4*>(bp + 256 * kq);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(THREADS) void mlp_backward_dx_kernel(
     {   // dA3 = dZ4 . W4  ->  dZ3 (in place over the staged H3 tile)
         f32x16 acc[1];
         zero_acc(acc);
-        tile_gemm<MLP_OUT, 1>(PT + MLP_OFF_WT4, wave * 32, ldsZ4, acc, lane);
+        tile_gemm<MLP_OUT, 1>(PT + MLP_OFF_TF4, wave, ldsZ4, acc, lane);
         epilogue_dact_inplace(acc[0], wave * 32 + (lane & 31), MLP_H3, ldsZ3, lane);
     }
     tile_store_lds<MLP_H2>(h2r, ldsZ2, tid);
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(THREADS) void mlp_backward_dx_kernel(
     {   // dA2 = dZ3 . W3  ->  dZ2
         f32x16 acc[1];
         zero_acc(acc);
-        tile_gemm<MLP_H3, 1>(PT + MLP_OFF_WT3, wave * 32, ldsZ3, acc, lane);
+        tile_gemm<MLP_H3, 1>(PT + MLP_OFF_TF3, wave, ldsZ3, acc, lane);
         epilogue_dact_inplace(acc[0], wave * 32 + (lane & 31), MLP_H2, ldsZ2, lane);
     }
     __syncthreads();                                       // Z3 / Z4 are dead from here: Z1 may overwrite them
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(THREADS) void mlp_backward_dx_kernel(
         tile_load<MLP_H1>(h1r, h1_saved, row0, n, tid);    // in flight during the MFMAs
         f32x16 acc[2];
         zero_acc(acc);
-        tile_gemm<MLP_H2, 2>(PT + MLP_OFF_WT2, wave * 64, ldsZ2, acc, lane);
+        tile_gemm<MLP_H2, 2>(PT + MLP_OFF_TF2, wave * 2, ldsZ2, acc, lane);
         tile_store_lds<MLP_H1>(h1r, ldsZ1, tid);
         __syncthreads();
         epilogue_dact_inplace(acc[0], wave * 64 + (lane & 31), MLP_H1, ldsZ1, lane);
@@ -606,7 +607,10 @@ __global__ __launch_bounds__(ADAM_THREADS) void mlp_adam_norm_kernel(const float
     }
 }
 
-__global__ __launch_bounds__(ADAM_THREADS) void mlp_adam_apply_kernel(float* __restrict__ P, float* __restrict__ PT,
+__global__ __launch_bounds__(ADAM_THREADS) void mlp_adam_apply_kernel(float* __restrict__ P, float* __restrict__ PF,
+                                                                      float* __restrict__ PT,
+                                                                      const int* __restrict__ idx_f,
+                                                                      const int* __restrict__ idx_t,
                                                                       const float* __restrict__ G,
                                                                       const float* __restrict__ mask,
                                                                       float* __restrict__ m, float* __restrict__ v,
@@ -641,27 +645,20 @@ __global__ __launch_bounds__(ADAM_THREADS) void mlp_adam_apply_kernel(float* __r
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     const float p = P[i] - mk * (step_size * (mi / denom));
     P[i] = p;
-    // transposes for the dX chain (each weight element also lands in PT)
-    if (i >= MLP_OFF_W2 && i < MLP_OFF_B2) {
-        const int j = i - MLP_OFF_W2, nn = j / MLP_H1, kk = j - nn * MLP_H1;
-        PT[MLP_OFF_WT2 + kk * MLP_H2 + nn] = p;
-    } else if (i >= MLP_OFF_W3 && i < MLP_OFF_B3) {
-        const int j = i - MLP_OFF_W3, nn = j / MLP_H2, kk = j - nn * MLP_H2;
-        PT[MLP_OFF_WT3 + kk * MLP_H3 + nn] = p;
-    } else if (i >= MLP_OFF_W4 && i < MLP_OFF_B4) {
-        const int j = i - MLP_OFF_W4, nn = j / MLP_H3, kk = j - nn * MLP_H3;
-        PT[MLP_OFF_WT4 + kk * MLP_OUT + nn] = p;
-    }
+    // keep the fragment-ordered copies the kernels stream in step with the master weights
+    const int jf = idx_f[i], jt = idx_t[i];
+    if (jf >= 0) PF[jf] = p;
+    if (jt >= 0) PT[jt] = p;
 }
 
 }  // namespace
 
-extern "C" hipError_t flyhip_launch_mlp_forward(const float* P, const float* x, int64_t n, float* mu_out,
+extern "C" hipError_t flyhip_launch_mlp_forward(const float* P, const float* PF, const float* x, int64_t n, float* mu_out,
                                                 float* v_out, float* out_save, float* h1_save, float* h2_save,
                                                 float* h3_save, void* stream)
 {
     const int grid = (int)((n + BM - 1) / BM);
-    hipLaunchKernelGGL(mlp_forward_kernel, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, x, (long)n,
+    hipLaunchKernelGGL(mlp_forward_kernel, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PF, x, (long)n,
                        mu_out, v_out, out_save, h1_save, h2_save, h3_save);
     return hipGetLastError();
 }
@@ -726,7 +723,8 @@ extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, 
     return hipGetLastError();
 }
 
-extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PT, const float* G, const float* mask, float* m,
+extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PF, float* PT, const int* idx_f, const int* idx_t,
+                                             const float* G, const float* mask, float* m,
                                              float* v, int* step, float lr, float beta1, float beta2, float eps,
                                              float max_norm, float grad_scale, float* norm_ws, void* stream)
 {
@@ -734,7 +732,7 @@ extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PT, const float* G
                        grad_scale, norm_ws, step);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(mlp_adam_apply_kernel, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, P, PT, G,
-                       mask, m, v, step, lr, beta1, beta2, eps, max_norm, grad_scale, norm_ws);
+    hipLaunchKernelGGL(mlp_adam_apply_kernel, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, P, PF, PT,
+                       idx_f, idx_t, G, mask, m, v, step, lr, beta1, beta2, eps, max_norm, grad_scale, norm_ws);
     return hipGetLastError();
 }

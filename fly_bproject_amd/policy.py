@@ -21,10 +21,45 @@ OFF_B3 = OFF_W3 + H3 * H2
 OFF_W4 = OFF_B3 + H3
 OFF_B4 = OFF_W4 + OUT * H3
 PACKED = OFF_B4 + OUT                      # 74272
-OFF_WT2 = 0
-OFF_WT3 = OFF_WT2 + H1 * H2
-OFF_WT4 = OFF_WT3 + H2 * H3
-PACKED_T = OFF_WT4 + H3 * OUT              # 53248
+OFF_F1 = 0
+OFF_F2 = OFF_F1 + H1 * IN_PAD
+OFF_F3 = OFF_F2 + H2 * H1
+OFF_F4 = OFF_F3 + H3 * H2
+FRAG = OFF_F4 + OUT * H3                   # 73728
+OFF_TF2 = 0
+OFF_TF3 = OFF_TF2 + H1 * H2
+OFF_TF4 = OFF_TF3 + H2 * H3
+FRAG_T = OFF_TF4 + H3 * OUT                # 53248
+
+
+def _frag_index(n, k, K):
+    """Fragment-order offset of element (n, k) of an operand with K reduced (csrc/mlp_layout.h)."""
+    h, kk = k // (K // 2), k % (K // 2)
+    return (((n // 32) * (K // 8) + kk // 4) * 64 + (h * 32 + n % 32)) * 4 + kk % 4
+
+
+def build_index_maps():
+    """int32 [PACKED] maps master index -> position in PF / PTF (-1: no copy)."""
+    import numpy as np
+    idx_f = np.full(PACKED, -1, np.int32)
+    idx_t = np.full(PACKED, -1, np.int32)
+    layers = [(OFF_W1, H1, IN_PAD, OFF_F1, None), (OFF_W2, H2, H1, OFF_F2, OFF_TF2),
+              (OFF_W3, H3, H2, OFF_F3, OFF_TF3), (OFF_W4, OUT, H3, OFF_F4, OFF_TF4)]
+    for li, (off_w, N, K, off_f, off_t) in enumerate(layers):
+        n, k = np.meshgrid(np.arange(N), np.arange(K), indexing="ij")
+        src = off_w + n * K + k
+        if li < 3:
+            idx_f[src] = off_f + _frag_index(n, k, K)
+        else:       # layer 4 forward: split-K over the four waves
+            w, h, kq, q = k // 32, (k % 32) // 16, (k % 16) // 4, k % 4
+            idx_f[src] = off_f + ((w * 4 + kq) * 64 + (h * 32 + n)) * 4 + q
+        if off_t is not None:   # W^T: K outputs, N reduced
+            idx_t[src] = off_t + _frag_index(k, n, N)
+    for name, idx, size in (("PF", idx_f, FRAG), ("PTF", idx_t, FRAG_T)):
+        used = idx[idx >= 0]
+        assert len(np.unique(used)) == len(used) and used.max() < size, name
+    assert (idx_f >= 0).sum() == FRAG and (idx_t >= 0).sum() == FRAG_T
+    return idx_f, idx_t
 
 
 class PackedPolicy:
@@ -32,7 +67,15 @@ class PackedPolicy:
         self.device = torch.device(device)
         self._lib = _lib.load()
         self.P = torch.zeros(PACKED, dtype=torch.float32, device=self.device)
-        self.PT = torch.zeros(PACKED_T, dtype=torch.float32, device=self.device)
+        self.PF = torch.zeros(FRAG, dtype=torch.float32, device=self.device)      # forward operands, fragment order
+        self.PT = torch.zeros(FRAG_T, dtype=torch.float32, device=self.device)    # W^T operands, fragment order
+        idx_f, idx_t = build_index_maps()
+        self.idx_f = torch.from_numpy(idx_f).to(self.device)
+        self.idx_t = torch.from_numpy(idx_t).to(self.device)
+        self._src_f = torch.nonzero(self.idx_f >= 0).squeeze(-1)
+        self._dst_f = self.idx_f[self._src_f].long()
+        self._src_t = torch.nonzero(self.idx_t >= 0).squeeze(-1)
+        self._dst_t = self.idx_t[self._src_t].long()
         P = self.P
         self.W1 = P[OFF_W1:OFF_B1].view(H1, IN_PAD)
         self.b1 = P[OFF_B1:OFF_W2]
@@ -63,14 +106,16 @@ class PackedPolicy:
             mask[idx.reshape(-1)] = 1.0
         self.grad_mask = mask
         assert int(mask.sum().item()) == 69587            # every reference parameter exactly once
-        self.refresh_transposes()
+        self.refresh()
 
-    def refresh_transposes(self):
-        """W^T copies streamed by the backward dX chain (call after the weights change)."""
+    def refresh(self):
+        """Rebuild the fragment-ordered copies from the master weights (after a load or any
+        out-of-band change of the parameters; mlp_adam_step keeps them in step by itself)."""
         with torch.no_grad():
-            self.PT[OFF_WT2:OFF_WT3].view(H1, H2).copy_(self.W2.t())
-            self.PT[OFF_WT3:OFF_WT4].view(H2, H3).copy_(self.W3.t())
-            self.PT[OFF_WT4:PACKED_T].view(H3, OUT).copy_(self.W4.t())
+            self.PF[self._dst_f] = self.P[self._src_f]
+            self.PT[self._dst_t] = self.P[self._src_t]
+
+    refresh_transposes = refresh
 
     def forward(self, x, want_mu=True, want_v=True, saves=None):
         """x f32 [..., 73] on the device -> (mu [..., 18] | None, v [..., 1] | None)."""
@@ -83,7 +128,7 @@ class PackedPolicy:
         v = torch.empty((n,), device=self.device) if want_v else None
         s = saves or {}
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
-        _lib.check(self._lib.mlp_forward(ptr(self.P), ptr(x2), C.c_int64(n), ptr(mu), ptr(v), ptr(s.get("out")),
+        _lib.check(self._lib.mlp_forward(ptr(self.P), ptr(self.PF), ptr(x2), C.c_int64(n), ptr(mu), ptr(v), ptr(s.get("out")),
                                          ptr(s.get("h1")), ptr(s.get("h2")), ptr(s.get("h3")), _lib.stream_ptr()),
                    "mlp_forward")
         return (mu.view(*lead, NACT) if want_mu else None), (v.view(*lead, 1) if want_v else None)
@@ -116,7 +161,7 @@ class PackedPolicy:
         s, d = self.saves, self.dz
         p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
         st = _lib.stream_ptr()
-        _lib.check(self._lib.mlp_forward(p(self.P), p(x), C.c_int64(n), None, None, p(s["out"]), p(s["h1"]),
+        _lib.check(self._lib.mlp_forward(p(self.P), p(self.PF), p(x), C.c_int64(n), None, None, p(s["out"]), p(s["h1"]),
                                          p(s["h2"]), p(s["h3"]), st), "mlp_forward")
         inv_b = 1.0 / float(global_rows if global_rows else n)
         _lib.check(self._lib.mlp_backward_dx(p(self.PT), p(s["out"]), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(action),
@@ -134,7 +179,8 @@ class PackedPolicy:
 
     def adam_step(self, grad_scale=1.0):
         p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
-        _lib.check(self._lib.mlp_adam_step(p(self.P), p(self.PT), p(self.G), p(self.grad_mask), p(self.exp_avg),
+        _lib.check(self._lib.mlp_adam_step(p(self.P), p(self.PF), p(self.PT), p(self.idx_f), p(self.idx_t), p(self.G),
+                                           p(self.grad_mask), p(self.exp_avg),
                                            p(self.exp_avg_sq), p(self.step), C.c_float(self.lr),
                                            C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
                                            C.c_float(self.max_norm), C.c_float(grad_scale), p(self._norm_ws),

@@ -108,6 +108,7 @@ class PPO:
         if getattr(self.args, "load", False):                       # ppo.py:147-149
             print("loaded from: ", str(self.args.load_path))
             self.net.load_state_dict(torch.load(self.args.load_path, map_location=dev, weights_only=True))
+        self._loaded = bool(getattr(self.args, "load", False))
         from .policy import PackedPolicy
         self.policy = PackedPolicy(self.net, dev)                   # parameters become views of one packed buffer
         self.net._policy = self.policy
@@ -193,6 +194,7 @@ class PPO:
                 self.optim.step()
                 self.optim_step += 1
                 k = j
+        self.policy.refresh()       # torch wrote the master weights: rebuild the fragment-ordered copies
 
     def _update_hip(self, obs, action, old_log_prob, target, advantage):
         """ppo.py:179-202 on the MFMA kernels: per minibatch one fused forward, the loss gradient +

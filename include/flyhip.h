@@ -172,15 +172,18 @@ int ppo_step_bookkeeping(const float* reward, int64_t n, float* score_acc, float
 /*
  * Actor-critic MLP on the matrix cores (fp32-in/fp32-accumulate MFMA), reference ppo.py:10-102
  * (`Net.pi` / `Net.v`; 73-256-128 shared trunk, 128-64-18 actor with ELU on the mean, 128-64-1
- * critic).  `params` is the packed buffer of MLP_PACKED_FLOATS floats laid out as documented in
- * fly_bproject_amd/csrc/mlp_layout.h.  x f32 [n][73].  Every output pointer is optional (NULL):
+ * critic).  `params` is the packed master buffer (MLP_PACKED_FLOATS_ABI floats, row-major layers:
+ * biases are read from it) and `params_frag` the same weights in MFMA fragment order
+ * (MLP_FRAG_FLOATS_ABI floats); layouts: fly_bproject_amd/csrc/mlp_layout.h.  x f32 [n][73].
+ * Every output pointer is optional (NULL):
  *   mu_out [n][18]  actor mean (after its ELU)        v_out [n]  critic value
  *   out_save [n][32], h1_save [n][256], h2_save [n][128], h3_save [n][128]: activations kept
  *   for the backward pass.
  */
 #define MLP_PACKED_FLOATS_ABI 74272
-#define MLP_PACKED_T_FLOATS_ABI 53248
-int mlp_forward(const float* params, const float* x, int64_t n, float* mu_out, float* v_out,
+#define MLP_FRAG_FLOATS_ABI 73728
+#define MLP_FRAG_T_FLOATS_ABI 53248
+int mlp_forward(const float* params, const float* params_frag, const float* x, int64_t n, float* mu_out, float* v_out,
                 float* out_save, float* h1_save, float* h2_save, float* h3_save, void* stream);
 
 
@@ -194,14 +197,16 @@ int mlp_forward(const float* params, const float* x, int64_t n, float* mu_out, f
  *   mlp_grad_w      : dW = dZ^T A and db = colsum(dZ) for all four layers into `grad`
  *                     (packed layout of `params`); `workspace` holds
  *                     mlp_grad_workspace_floats() floats.
- *   mlp_adam_step   : grad *= grad_scale; clip_grad_norm_(max_norm); Adam with torch defaults;
- *                     refreshes params_t (the transposed weights).  `mask` (packed layout, 0/1)
+ *   mlp_adam_step   : grad *= grad_scale; clip_grad_norm_(max_norm); Adam with torch defaults on
+ *                     `params`; every updated weight is also scattered into params_frag /
+ *                     params_t_frag through idx_frag / idx_t_frag (int32 [MLP_PACKED_FLOATS_ABI],
+ *                     -1 = no copy).  `mask` (packed layout, 0/1)
  *                     freezes padding and structural zeros.  `step` is a device int counter;
  *                     `norm_ws` is a device scratch of >= 128 floats, norm_ws[0] returns the
  *                     pre-clip gradient norm.
  */
 int64_t mlp_grad_workspace_floats(void);
-int mlp_backward_dx(const float* params_t, const float* out_saved, const float* h1_saved,
+int mlp_backward_dx(const float* params_t_frag, const float* out_saved, const float* h1_saved,
                     const float* h2_saved, const float* h3_saved, const float* action,
                     const float* old_logp, const float* adv, const float* target, const float* var,
                     int64_t n, float inv_batch, float clip, float* dz4, float* dz3, float* dz2,
@@ -209,7 +214,8 @@ int mlp_backward_dx(const float* params_t, const float* out_saved, const float* 
 int mlp_grad_w(const float* x, const float* h1_saved, const float* h2_saved, const float* h3_saved,
                const float* dz1, const float* dz2, const float* dz3, const float* dz4, int64_t n,
                float* workspace, float* grad, void* stream);
-int mlp_adam_step(float* params, float* params_t, const float* grad, const float* mask, float* exp_avg,
+int mlp_adam_step(float* params, float* params_frag, float* params_t_frag, const int32_t* idx_frag,
+                  const int32_t* idx_t_frag, const float* grad, const float* mask, float* exp_avg,
                   float* exp_avg_sq, int32_t* step, float lr, float beta1, float beta2, float eps,
                   float max_norm, float grad_scale, float* norm_ws, void* stream);
 

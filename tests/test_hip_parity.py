@@ -111,6 +111,29 @@ def test_pack_reward_vs_reference_golden(golden, n, variant, ecs):
     env.exit()
 
 
+def test_walking_reward_mode_vs_oracle():
+    """reward_mode 1 = the walking formula the reference keeps commented out (fly.py:747-748);
+    no reference run can pin it, the oracle restates the commented expression."""
+    from fly_bproject_amd.fly import Fly
+    from tests.hip_helpers import make_args
+    n = 512
+    cfg = O.default_config(n)
+    cfg.reward_mode = 1
+    env = Fly(make_args(n, reward="walking"))
+    assert env.params.reward_mode == 1
+    for t, (s, a) in enumerate(_rollout_states(O.default_config(n), n, 30, 0.7, 21)[10:]):
+        push_state(env, s)
+        env.step(cuda(a))
+        got = pull_state(env)
+        O.env_step(cfg, s, a)
+        z, ori = s.root[:, 2], s.root[:, 5] ** 2 + s.root[:, 6] ** 2
+        ok = (np.abs(z - 1.1) > 1e-3) & (np.abs(z - 1.4) > 1e-3) & (np.abs(z - 2.1) > 1e-3) & \
+            (np.abs(ori - 0.98) > 1e-3) & (np.abs(ori - 0.5) > 1e-3) & (s.reset == got.reset)
+        # progress_reward = (pot - prev_pot) * 2 with pot ~ -6e4: absolute fp32 noise ~ 0.02
+        np.testing.assert_allclose(got.reward[ok], s.reward[ok], rtol=1e-3, atol=0.05)
+    env.exit()
+
+
 def _rollout_states(cfg, n, steps, noise, seed):
     rng = np.random.default_rng(seed)
     s = O.EnvState(n)
