@@ -39,6 +39,12 @@ extern "C" hipError_t flyhip_launch_bookkeeping(const float* reward, int64_t n, 
                                                 float* action_var, int nvar, float var_decay, float var_min,
                                                 void* stream);
 
+extern "C" hipError_t flyhip_launch_dqn_eps_greedy(const float* q, const float* coin_u, const float* rand_u, float epsilon,
+                                                   int A, float* act_out, int64_t n, void* stream);
+extern "C" hipError_t flyhip_launch_dqn_huber_td(const float* q_table, const float* act, const float* reward,
+                                                 const float* q_next, const float* done, float discount, int A, int64_t B,
+                                                 float* dq, float* loss_part, void* stream);
+
 struct FlyEnv {
     FlyConfig host;
     FlyConfig* dev;
@@ -239,6 +245,28 @@ int mlp_adam_step(float* params, float* params_frag, float* params_t_frag, const
     hipError_t e = flyhip_launch_mlp_adam(params, params_frag, params_t_frag, idx_frag, idx_t_frag, grad, mask, exp_avg, exp_avg_sq, step, lr, beta1, beta2,
                                           eps, max_norm, grad_scale, norm_ws, stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_adam_step launch");
+    return FLY_OK;
+}
+
+int dqn_eps_greedy(const float* q, const float* coin_u, const float* rand_u, float epsilon, int32_t A,
+                   float* act_out, int64_t n, void* stream)
+{
+    if (!q || !coin_u || !rand_u || !act_out) return fail(FLY_E_ARG, "dqn_eps_greedy: null pointer");
+    if (n <= 0 || A < 2) return fail(FLY_E_ARG, "dqn_eps_greedy: need n > 0 and A >= 2");
+    hipError_t e = flyhip_launch_dqn_eps_greedy(q, coin_u, rand_u, epsilon, A, act_out, n, stream);
+    if (e != hipSuccess) return hip_fail(e, "dqn_eps_greedy launch");
+    return FLY_OK;
+}
+
+int dqn_huber_td(const float* q_table, const float* act, const float* reward, const float* q_next,
+                 const float* done, float discount, int32_t A, int64_t B, float* dq, float* loss_part,
+                 void* stream)
+{
+    if (!q_table || !act || !reward || !q_next || !done || !dq || !loss_part)
+        return fail(FLY_E_ARG, "dqn_huber_td: null pointer");
+    if (B <= 0 || A < 2) return fail(FLY_E_ARG, "dqn_huber_td: need B > 0 and A >= 2");
+    hipError_t e = flyhip_launch_dqn_huber_td(q_table, act, reward, q_next, done, discount, A, B, dq, loss_part, stream);
+    if (e != hipSuccess) return hip_fail(e, "dqn_huber_td launch");
     return FLY_OK;
 }
 

@@ -51,19 +51,23 @@ __device__ __forceinline__ void tile_gemm(const float* __restrict__ Wf, int tile
     const float* bp[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) bp[t] = Wf + (long)(tile0 + t) * (K / 8) * 256 + lane * 4;
+    // operands of k-quad kq+1 (A from LDS, B from L2) are requested before the MFMAs of k-quad kq
     float4 bnext[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) bnext[t] = *reinterpret_cast<const float4*>(bp[t]);
+    float4 anext = *reinterpret_cast<const float4*>(ap);
 #pragma unroll 4
     for (int kq = 0; kq < K / 8; ++kq) {
         float4 b[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) b[t] = bnext[t];
+        const float4 a = anext;
         if (kq + 1 < K / 8) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) bnext[t] = *reinterpret_cast<const float4*>(bp[t] + 256 * (kq + 1));
+            anext = *reinterpret_cast<const float4*>(ap + 4 * (kq + 1));
         }
-        const float4 a = *reinterpret_cast<const float4*>(ap + 4 * kq);
+        __builtin_amdgcn_sched_barrier(0);              // keep the prefetch ahead of this k-quad's MFMAs
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
@@ -71,6 +75,7 @@ __device__ __forceinline__ void tile_gemm(const float* __restrict__ Wf, int tile
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -492,25 +497,44 @@ __device__ void grad_w_layer(const GradWLayer& L, long nrows, int wg, float* lds
         if (more) load_chunk(c0 + GW_ROWS);                     // in flight during the MFMAs below
         const float* bz = lds + cur * BUF;
         const float* ba = bz + GW_ROWS * N;
-        if (tid < N) {
-#pragma unroll 8
-            for (int rr = 0; rr < GW_ROWS; ++rr) bsum += bz[rr * N + tid];
+        {   // column sums of dZ (bias gradient): all threads take a slice of the 32 rows of one column
+            constexpr int PARTS = (GW_THREADS / N) < 1 ? 1 : ((GW_THREADS / N) > GW_ROWS ? GW_ROWS : (GW_THREADS / N));
+            constexpr int RPP = GW_ROWS / PARTS;
+            const int colb = tid % N, part = tid / N;
+            if (part < PARTS) {
+#pragma unroll
+                for (int rr = 0; rr < RPP; ++rr) bsum += bz[(part * RPP + rr) * N + colb];
+            }
         }
         if (active) {
             const float* zp = bz + h * N + wn * (TNW * 32) + r;
             const float* ap = ba + h * KPAD + wk * (TKW * 32) + r;
-#pragma unroll 4
+            // operands of step st+1 are read from LDS before the MFMAs of step st are issued
+            float zn[TNW], an[TKW];
+#pragma unroll
+            for (int a = 0; a < TNW; ++a) zn[a] = zp[32 * a];
+#pragma unroll
+            for (int b = 0; b < TKW; ++b) an[b] = ap[32 * b];
+#pragma unroll
             for (int st = 0; st < GW_ROWS / 2; ++st) {
                 float zv[TNW], av[TKW];
 #pragma unroll
-                for (int a = 0; a < TNW; ++a) zv[a] = zp[2 * st * N + 32 * a];
+                for (int a = 0; a < TNW; ++a) zv[a] = zn[a];
 #pragma unroll
-                for (int b = 0; b < TKW; ++b) av[b] = ap[2 * st * KPAD + 32 * b];
+                for (int b = 0; b < TKW; ++b) av[b] = an[b];
+                if (st + 1 < GW_ROWS / 2) {
+#pragma unroll
+                    for (int a = 0; a < TNW; ++a) zn[a] = zp[2 * (st + 1) * N + 32 * a];
+#pragma unroll
+                    for (int b = 0; b < TKW; ++b) an[b] = ap[2 * (st + 1) * KPAD + 32 * b];
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep the prefetch reads ahead of this step's MFMAs
 #pragma unroll
                 for (int a = 0; a < TNW; ++a)
 #pragma unroll
                     for (int b = 0; b < TKW; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(zv[a], av[b], acc[a][b], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (more) store_chunk(lds + (cur ^ 1) * BUF);
@@ -533,7 +557,18 @@ __device__ void grad_w_layer(const GradWLayer& L, long nrows, int wg, float* lds
                 }
             }
     }
-    if (tid < N) out[tid * (KOUT + 1) + KOUT] = bsum;
+    {   // combine the per-thread slices of the bias gradient through LDS (fixed order)
+        constexpr int PARTS = (GW_THREADS / N) < 1 ? 1 : ((GW_THREADS / N) > GW_ROWS ? GW_ROWS : (GW_THREADS / N));
+        __syncthreads();
+        if (tid / N < PARTS) lds[tid] = bsum;
+        __syncthreads();
+        if (tid < N) {
+            float s = 0.0f;
+#pragma unroll
+            for (int p = 0; p < PARTS; ++p) s += lds[p * N + tid];
+            out[tid * (KOUT + 1) + KOUT] = s;
+        }
+    }
 }
 
 __global__ __launch_bounds__(GW_THREADS) void mlp_grad_w_kernel(GradWTable T, long nrows)
@@ -550,31 +585,39 @@ __global__ __launch_bounds__(GW_THREADS) void mlp_grad_w_kernel(GradWTable T, lo
         grad_w_layer<MLP_H1, MLP_IN, 96, MLP_IN_PAD, 8, 1, 1, 3>(T.l[0], nrows, b, lds_dyn);
 }
 
-// sum the per-workgroup partials into the packed gradient buffer (layout of P); fixed order, eight
-// independent partial sums per thread so that eight loads are in flight.
+// sum the per-workgroup partials into the packed gradient buffer (layout of P).  A block handles 64
+// consecutive elements; its four waves each take every fourth partial slab (coalesced 256-byte
+// reads, eight loads in flight per lane) and the four partial sums meet in LDS.  Fixed order.
 __global__ __launch_bounds__(256) void mlp_grad_reduce_kernel(GradWTable T, float* __restrict__ G)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= MLP_PACKED_FLOATS) return;
-    int layer, off_w, off_b, N, KP;
-    if (i < MLP_OFF_W2) { layer = 0; off_w = MLP_OFF_W1; off_b = MLP_OFF_B1; N = MLP_H1; KP = MLP_IN_PAD; }
-    else if (i < MLP_OFF_W3) { layer = 1; off_w = MLP_OFF_W2; off_b = MLP_OFF_B2; N = MLP_H2; KP = MLP_H1; }
-    else if (i < MLP_OFF_W4) { layer = 2; off_w = MLP_OFF_W3; off_b = MLP_OFF_B3; N = MLP_H3; KP = MLP_H2; }
-    else { layer = 3; off_w = MLP_OFF_W4; off_b = MLP_OFF_B4; N = MLP_OUT; KP = MLP_H3; }
-    const float* part = layer == 0 ? T.l[0].partial : layer == 1 ? T.l[1].partial : layer == 2 ? T.l[2].partial : T.l[3].partial;
-    const int wgs = layer == 0 ? T.l[0].wgs : layer == 1 ? T.l[1].wgs : layer == 2 ? T.l[2].wgs : T.l[3].wgs;
-    long idx;
-    if (i < off_b) { const int rr = (i - off_w) / KP, cc = (i - off_w) - rr * KP; idx = (long)rr * (KP + 1) + cc; }
-    else idx = (long)(i - off_b) * (KP + 1) + KP;
-    const long stride = (long)N * (KP + 1);
-    float s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int w = 0;
-    for (; w + 8 <= wgs; w += 8) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    float total = 0.0f;
+    if (i < MLP_PACKED_FLOATS) {
+        int layer, off_w, off_b, N, KP;
+        if (i < MLP_OFF_W2) { layer = 0; off_w = MLP_OFF_W1; off_b = MLP_OFF_B1; N = MLP_H1; KP = MLP_IN_PAD; }
+        else if (i < MLP_OFF_W3) { layer = 1; off_w = MLP_OFF_W2; off_b = MLP_OFF_B2; N = MLP_H2; KP = MLP_H1; }
+        else if (i < MLP_OFF_W4) { layer = 2; off_w = MLP_OFF_W3; off_b = MLP_OFF_B3; N = MLP_H3; KP = MLP_H2; }
+        else { layer = 3; off_w = MLP_OFF_W4; off_b = MLP_OFF_B4; N = MLP_OUT; KP = MLP_H3; }
+        const float* part = layer == 0 ? T.l[0].partial : layer == 1 ? T.l[1].partial : layer == 2 ? T.l[2].partial : T.l[3].partial;
+        const int wgs = layer == 0 ? T.l[0].wgs : layer == 1 ? T.l[1].wgs : layer == 2 ? T.l[2].wgs : T.l[3].wgs;
+        long idx;
+        if (i < off_b) { const int rr = (i - off_w) / KP, cc = (i - off_w) - rr * KP; idx = (long)rr * (KP + 1) + cc; }
+        else idx = (long)(i - off_b) * (KP + 1) + KP;
+        const long stride = (long)N * (KP + 1);
+        float s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int w = wave;
+        for (; w + 28 < wgs; w += 32) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s8[u] += part[(w + u) * stride + idx];
+            for (int u = 0; u < 8; ++u) s8[u] += part[(w + 4 * u) * stride + idx];
+        }
+        for (int u = 0; w < wgs; w += 4, ++u) s8[u & 7] += part[w * stride + idx];
+        total = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
     }
-    for (; w < wgs; ++w) s8[w & 7] += part[w * stride + idx];
-    G[i] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    red[wave][lane] = total;
+    __syncthreads();
+    if (wave == 0 && i < MLP_PACKED_FLOATS) G[i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -718,7 +761,7 @@ extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, 
     hipLaunchKernelGGL(mlp_grad_w_kernel, dim3(first), dim3(GW_THREADS), lds_bytes, (hipStream_t)stream, T, (long)n);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((MLP_PACKED_FLOATS + 255) / 256), dim3(256), 0,
+    hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((MLP_PACKED_FLOATS + 63) / 64), dim3(256), 0,
                        (hipStream_t)stream, T, grad_out);
     return hipGetLastError();
 }

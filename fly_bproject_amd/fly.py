@@ -137,6 +137,11 @@ class Fly:
                    "fly_reset_masked")
         return True
 
+    def reset_async(self):
+        """fly.py:446-480 without the host sync of the boolean return value."""
+        _lib.check(self._lib.fly_reset_masked(self._handle, C.byref(self._bufs), _lib.stream_ptr()),
+                   "fly_reset_masked")
+
     def simulate(self):
         """fly.py:482-485."""
         _lib.check(self._lib.fly_integrate(self._handle, C.byref(self._bufs), _lib.stream_ptr()), "fly_integrate")

@@ -219,6 +219,23 @@ int mlp_adam_step(float* params, float* params_frag, float* params_t_frag, const
                   float* exp_avg_sq, int32_t* step, float lr, float beta1, float beta2, float eps,
                   float max_norm, float grad_scale, float* norm_ws, void* stream);
 
+
+/*
+ * DQN variant (reference UselessFiles/dqn.py, BASELINE configs[4]).
+ *   dqn_eps_greedy (dqn.py:89-100): per env, the FIRST maximal entry of its Q row -> idx/(A-1);
+ *       act = coin_u < epsilon ? rand_u : that; act_out = 2*(act-0.5).  q f32 [n][A]; coin_u,
+ *       rand_u, act_out f32 [n].
+ *   dqn_huber_td (dqn.py:68-79): idx = round(0.5*(act+1)*(A-1)); target = reward + discount *
+ *       max_a q_next * done; loss = mean smooth_l1(q_table[b,idx] - target).  Writes the gradient
+ *       of that loss w.r.t. q_table into dq [B][A] and per-256-row partial loss sums into
+ *       loss_part [ceil(B/256)].
+ */
+int dqn_eps_greedy(const float* q, const float* coin_u, const float* rand_u, float epsilon, int32_t A,
+                   float* act_out, int64_t n, void* stream);
+int dqn_huber_td(const float* q_table, const float* act, const float* reward, const float* q_next,
+                 const float* done, float discount, int32_t A, int64_t B, float* dq, float* loss_part,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

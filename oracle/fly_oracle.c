@@ -355,3 +355,38 @@ void orc_net_forward(const float* const* w, const float* const* b, const float* 
         }
     }
 }
+
+/* ---- a13: UselessFiles/dqn.py:89-100 (act) and :64-85 (update's TD loss) -------------------- */
+void orc_dqn_eps_greedy(const float* q, const float* coin_u, const float* rand_u, float epsilon, int A,
+                        float* act_out, int64_t n)
+{
+    for (int64_t e = 0; e < n; ++e) {
+        const float* row = q + e * A;
+        int idx = 0;
+        for (int a = 1; a < A; ++a) if (row[a] > row[idx]) idx = a;      /* first maximal entry, :95-96 */
+        float true_act = (float)idx / (float)(A - 1);                      /* :97 */
+        float coin = coin_u[e] < epsilon ? 1.0f : 0.0f;                    /* :90 */
+        float act = coin * rand_u[e] + (1.0f - coin) * true_act;           /* :99 */
+        act_out[e] = 2.0f * (act - 0.5f);                                  /* :100 */
+    }
+}
+
+void orc_dqn_huber_td(const float* q_table, const float* act, const float* reward, const float* q_next,
+                      const float* done, float discount, int A, int64_t B, float* dq, float* loss_out)
+{
+    double loss = 0.0;
+    for (int64_t b = 0; b < B; ++b) {
+        float a01 = 0.5f * (act[b] + 1.0f);
+        int idx = (int)rintf(a01 * (float)(A - 1));                        /* torch.round, :71 */
+        float mx = q_next[b * A];
+        for (int a = 1; a < A; ++a) if (q_next[b * A + a] > mx) mx = q_next[b * A + a];   /* :75 */
+        float target = reward[b] + discount * mx * done[b];                /* :77 */
+        float d = q_table[b * A + idx] - target;
+        float h = fabsf(d) < 1.0f ? 0.5f * d * d : fabsf(d) - 0.5f;        /* smooth_l1, :78 */
+        loss += h;
+        for (int a = 0; a < A; ++a) dq[b * A + a] = 0.0f;
+        float g = d < -1.0f ? -1.0f : (d > 1.0f ? 1.0f : d);
+        dq[b * A + idx] = g / (float)B;
+    }
+    *loss_out = (float)(loss / (double)B);
+}

@@ -97,4 +97,9 @@ void orc_td_gae(const float* reward, const float* v, const float* v_next, const 
 /* ppo.py:10-102: out = head(shared(x)); head 0 = pi (18 outputs, ELU), 1 = v (1 output) */
 void orc_net_forward(const float* const* w, const float* const* b, const float* x, int64_t n,
                      int head, float* out);
+/* UselessFiles/dqn.py:89-100 and :64-85 */
+void orc_dqn_eps_greedy(const float* q, const float* coin_u, const float* rand_u, float epsilon, int A,
+                        float* act_out, int64_t n);
+void orc_dqn_huber_td(const float* q_table, const float* act, const float* reward, const float* q_next,
+                      const float* done, float discount, int A, int64_t B, float* dq, float* loss_out);
 #endif

@@ -152,3 +152,20 @@ def net_forward(state_dict, x, head):
     out = np.empty((x.shape[0], NDOF if head == 0 else 1), np.float32)
     lib().orc_net_forward(w, b, _p(x), C.c_int64(x.shape[0]), C.c_int(head), _p(out))
     return out
+
+
+def dqn_eps_greedy(q, coin_u, rand_u, epsilon):
+    q, coin_u, rand_u = _f32(q), _f32(coin_u), _f32(rand_u)
+    out = np.empty((q.shape[0],), np.float32)
+    lib().orc_dqn_eps_greedy(_p(q), _p(coin_u), _p(rand_u), C.c_float(epsilon), C.c_int(q.shape[1]), _p(out),
+                             C.c_int64(q.shape[0]))
+    return out
+
+
+def dqn_huber_td(q_table, act, reward, q_next, done, discount=0.99):
+    q_table, act, reward, q_next, done = _f32(q_table), _f32(act), _f32(reward), _f32(q_next), _f32(done)
+    dq = np.empty_like(q_table)
+    loss = C.c_float()
+    lib().orc_dqn_huber_td(_p(q_table), _p(act), _p(reward), _p(q_next), _p(done), C.c_float(discount),
+                           C.c_int(q_table.shape[1]), C.c_int64(q_table.shape[0]), _p(dq), C.byref(loss))
+    return dq, loss.value

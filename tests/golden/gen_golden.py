@@ -16,6 +16,7 @@ Fixtures
   g5_sample   MultivariateNormal sample / log_prob / clip   ppo.py:213-220
   g6_gae      PPO.make_data                                 ppo.py:157-171
   g7_update   PPO.update (75 optimizer steps)               ppo.py:173-202
+  g8_dqn      DQN.act / DQN.update (TD loss + gradient)     UselessFiles/dqn.py:64-100
 """
 import os
 import sys
@@ -374,6 +375,57 @@ def gen_gae_update(rng, net):
     np.savez_compressed(os.path.join(HERE, "g7_update.npz"), **out7)
 
 
+def gen_dqn(rng):
+    """The reference's own DQN.act and DQN.update driven through a bare object (no env, a stub
+    replay that returns fixed tensors).  num_obs is 73 here (the stale default 84 does not match
+    the current Fly)."""
+    import UselessFiles.dqn as ref_dqn
+    n, A = 96, 18
+    torch.manual_seed(5)
+    d = ref_dqn.DQN.__new__(ref_dqn.DQN)
+    d.args = types.SimpleNamespace(num_envs=n, sim_device="cpu")
+    d.act_space, d.discount, d.mini_batch_size = A, 0.99, 4
+    d.batch_size = n * d.mini_batch_size
+    d.tau = 0.995
+    d.q = ref_dqn.Net(num_obs=NO, num_act=A)
+    d.q_target = ref_dqn.Net(num_obs=NO, num_act=A)
+    ref_dqn.soft_update(d.q, d.q_target, tau=0.0)
+    d.optimizer = torch.optim.Adam(d.q.parameters(), lr=3e-4)
+    out = {"q_" + k: v.numpy().copy() for k, v in d.q.state_dict().items()}
+    obs = torch.from_numpy(rng.normal(0, 1, (n, NO)).astype(np.float32))
+    for tag, eps in (("e08", 0.8), ("e001", 0.01)):
+        torch.manual_seed(77)
+        coin_u = torch.rand(n); rand_u = torch.rand(n)              # the two draws of dqn.py:90-92, in order
+        torch.manual_seed(77)
+        act = d.act(obs, eps)
+        with torch.no_grad():
+            out[tag + "_q"] = d.q(obs).numpy()
+        out.update({tag + "_coin_u": coin_u.numpy(), tag + "_rand_u": rand_u.numpy(), tag + "_act": act.numpy()})
+    out["obs"] = obs.numpy()
+    B = d.batch_size
+    b_obs = torch.from_numpy(rng.normal(0, 1, (B, NO)).astype(np.float32))
+    b_next = torch.from_numpy(rng.normal(0, 1, (B, NO)).astype(np.float32))
+    b_act = torch.from_numpy((rng.integers(0, A, B) / (A - 1) * 2 - 1).astype(np.float32))
+    b_rew = torch.from_numpy(rng.normal(0.5, 1.5, B).astype(np.float32))
+    b_done = torch.from_numpy((rng.random(B) < 0.9).astype(np.float32))
+    d.replay = types.SimpleNamespace(sample=lambda m: (b_obs, b_act, b_rew, b_next, b_done))
+    grabbed = {}
+    with torch.no_grad():
+        q_table = d.q(b_obs).numpy().copy()
+        q_next = d.q_target(b_next).numpy().copy()
+    def _grab(mod, inp, outp):          # gradient of the loss w.r.t. the Q table (returns None: output unchanged)
+        outp.register_hook(lambda g: grabbed.__setitem__("dq", g.clone()))
+    handle = d.q.net[-1].register_forward_hook(_grab)
+    loss = d.update()
+    handle.remove()
+    out.update(b_act=b_act.numpy(), b_rew=b_rew.numpy(), b_done=b_done.numpy(), q_table=q_table, q_next=q_next,
+               loss=loss.detach().numpy(), dq=grabbed["dq"].numpy())
+    out.update({"q1_" + k: v.numpy().copy() for k, v in d.q.state_dict().items()})
+    out.update({"qt1_" + k: v.numpy().copy() for k, v in d.q_target.state_dict().items()})
+    out.update(b_obs=b_obs.numpy(), b_next=b_next.numpy())
+    np.savez_compressed(os.path.join(HERE, "g8_dqn.npz"), **out)
+
+
 def main():
     rng = np.random.default_rng(20250202)
     O.build()
@@ -382,6 +434,7 @@ def main():
     net = gen_net(rng)
     gen_sample(rng)
     gen_gae_update(rng, net)
+    gen_dqn(rng)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))
