@@ -192,7 +192,7 @@ def cpu_baseline(num_envs):
 
 def main():
     a = parse()
-    from fly_bproject_amd.dist import broadcast_parameters, init_from_env
+    from fly_bproject_amd.dist import broadcast_policy, init_from_env
     from fly_bproject_amd.ppo import PPO
 
     rank, local_rank, world = init_from_env("cuda")
@@ -202,7 +202,7 @@ def main():
     args = make_args(a.num_envs, sim_device=dev, rank=rank, world_size=world)
     with quiet():
         agent = PPO(args)
-    broadcast_parameters(agent.net)
+    broadcast_policy(agent)
     T = agent.rollout_size
 
     def iteration():

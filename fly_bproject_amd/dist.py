@@ -49,8 +49,8 @@ def init_from_env(device_type="cuda"):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = "nccl" if device_type == "cuda" else "gloo"    # "nccl" is RCCL on ROCm
-        if device_type == "cuda":
+        backend = os.environ.get("FLY_DIST_BACKEND") or ("nccl" if device_type == "cuda" else "gloo")   # "nccl" is RCCL on ROCm
+        if device_type == "cuda" and backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
@@ -62,4 +62,17 @@ def init_from_env(device_type="cuda"):
 def broadcast_parameters(module, src=0):
     if dist.is_initialized() and dist.get_world_size() > 1:
         for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src=src)
+            if t.data.is_contiguous():
+                dist.broadcast(t.data, src=src)
+            else:                                   # a strided view (e.g. of a packed buffer)
+                tmp = t.data.contiguous()
+                dist.broadcast(tmp, src=src)
+                t.data.copy_(tmp)
+
+
+def broadcast_policy(agent, src=0):
+    """Replicate rank `src`'s policy: ONE broadcast of the packed parameter buffer, then rebuild
+    the fragment-ordered copies the kernels stream."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(agent.policy.P, src=src)
+        agent.policy.refresh()

@@ -96,7 +96,11 @@ class PPO:
         self.all_log_prob = torch.zeros((T, n), device=dev)
         self.all_advantage = torch.zeros((T, n, 1), device=dev)
         self._target = torch.zeros((T, n, 1), device=dev)
-        self._eps = torch.zeros((n, self.num_acts), device=dev)
+        self._eps_all = torch.zeros((T, n, self.num_acts), device=dev)   # one normal_() per rollout
+        self._mu = torch.zeros((n, self.num_acts), device=dev)
+        self.use_graph = bool(getattr(args, "graph", False))
+        self._graphs = {}
+        self._fwd_args = None
         self._score_acc = torch.zeros((), device=dev)
         self.env.bind_obs(self._obs_ring[0])                        # first policy input: zeros (Q8)
 
@@ -218,32 +222,72 @@ class PPO:
                 k = j
 
     # ------------------------------------------------------------------------------------------
+    def _prepare_step_args(self):
+        """Every pointer of step t is a fixed row of a preallocated rollout tensor, so the ctypes
+        argument tuples of the four launches are built ONCE per t: a step then costs four foreign
+        calls and two attribute stores on the host (the rollout was host-bound at ~50 us/step
+        against ~35 us of GPU work)."""
+        T, n = self.rollout_size, int(self.args.num_envs)
+        P = C.c_void_p
+        pol = self.policy
+        self._obs_rows = [self._obs_ring[t] for t in range(T + 1)]
+        self._reward_rows = [self.all_reward[t].view(-1) for t in range(T)]
+        self._act_rows = [self.all_acts[t] for t in range(T)]
+        fwd, smp, book, bufs = [], [], [], []
+        for t in range(T):
+            fwd.append((P(pol.P.data_ptr()), P(pol.PF.data_ptr()), P(self._obs_rows[t].data_ptr()), C.c_int64(n),
+                        P(self._mu.data_ptr()), None, None, None, None, None))
+            smp.append((P(self._mu.data_ptr()), P(self.action_var.data_ptr()), P(self._eps_all[t].data_ptr()),
+                        P(self._act_rows[t].data_ptr()), P(self.all_log_prob[t].data_ptr()), C.c_int64(n)))
+            book.append((P(self._reward_rows[t].data_ptr()), C.c_int64(n), P(self._score_acc.data_ptr()),
+                         C.c_float(1.0 / self.num_eval_freq), P(self.action_var.data_ptr()), C.c_int(self.num_acts)))
+            bufs.append((self._obs_rows[t + 1].data_ptr(), self._reward_rows[t].data_ptr()))
+        self._fwd_args, self._smp_args, self._book_args, self._buf_ptrs = fwd, smp, book, bufs
+        self._var_min = C.c_float(0.01)
+
+    def _launch_step(self, t):
+        """The device work of one env step (ppo.py:213-237): four launches, no host logic.  Rows of
+        the rollout are written in place (obs row t+1, action/log-prob/reward rows t)."""
+        lib, env = self._lib, self.env
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if t == 0:
+            self._eps_all.normal_(generator=self._gen)              # the eps of MultivariateNormal.sample, whole rollout
+        rc = lib.mlp_forward(*self._fwd_args[t], st)                # ppo.py:214
+        rc |= lib.ppo_sample_logprob(*self._smp_args[t], st)        # ppo.py:215-220, :227
+        env.obs_buf, env.reward_buf = self._obs_rows[t + 1], self._reward_rows[t]      # ppo.py:228-229
+        env._bufs.obs, env._bufs.reward = self._buf_ptrs[t]
+        rc |= lib.fly_step(env._handle, C.c_void_p(self._act_rows[t].data_ptr()), C.byref(env._bufs), st)  # ppo.py:223
+        # ppo.py:230 (all_done): see the property.  ppo.py:233 + :236-237 in one tiny launch:
+        rc |= lib.ppo_step_bookkeeping(*self._book_args[t], C.c_float(0.0 if self.args.testing else 0.00001),
+                                       self._var_min, st)
+        if rc:
+            _lib.check(rc, "rollout step")
+        env.render_count += 1
+
     def run(self):
-        """ppo.py:204-264: one env step of the rollout (and an update when the rollout is full)."""
+        """ppo.py:204-264: one env step of the rollout (and an update when the rollout is full).
+        `graph=True` replays the step from a captured hipGraph instead (measured slower than the
+        lean eager path on this stack: ~70 vs ~40 us per step; kept for experiments)."""
         t = self.mini_batch_number
-        obs = self._obs_ring[t]                                     # == env.obs_buf (ppo.py:210)
         end = self.env.end
-
+        if self._fwd_args is None:
+            self._prepare_step_args()
         with torch.no_grad():
-            mu = self.net.pi(obs)                                   # ppo.py:214
-            self._eps.normal_(generator=self._gen)                  # the eps of MultivariateNormal.sample
-            action = self.all_acts[t]
-            _lib.check(self._lib.ppo_sample_logprob(                # ppo.py:215-220, :227
-                C.c_void_p(mu.data_ptr()), C.c_void_p(self.action_var.data_ptr()),
-                C.c_void_p(self._eps.data_ptr()), C.c_void_p(action.data_ptr()),
-                C.c_void_p(self.all_log_prob[t].data_ptr()), C.c_int64(mu.shape[0]), _lib.stream_ptr()),
-                "ppo_sample_logprob")
-
-            self.env.bind_obs(self._obs_ring[t + 1])                # next_obs row (ppo.py:228)
-            self.env.bind_reward(self.all_reward[t])                # reward row (ppo.py:229)
-            self.env.step(action)                                   # ppo.py:223
-            # ppo.py:230 (all_done): see the property.  ppo.py:233 + :236-237 in one tiny launch:
-            _lib.check(self._lib.ppo_step_bookkeeping(
-                C.c_void_p(self.env.reward_buf.data_ptr()), C.c_int64(self.env.reward_buf.numel()),
-                C.c_void_p(self._score_acc.data_ptr()), C.c_float(1.0 / self.num_eval_freq),
-                C.c_void_p(self.action_var.data_ptr()), C.c_int(self.num_acts),
-                C.c_float(0.0 if self.args.testing else 0.00001), C.c_float(0.01), _lib.stream_ptr()),
-                "ppo_step_bookkeeping")
+            if not self.use_graph or self.run_step < self.rollout_size:
+                self._launch_step(t)
+            else:
+                key = (t, bool(self.args.testing))
+                g = self._graphs.get(key)
+                if g is None:
+                    g = torch.cuda.CUDAGraph()
+                    g.register_generator_state(self._gen)
+                    torch.cuda.synchronize(self.device)
+                    with torch.cuda.graph(g):
+                        self._launch_step(t)
+                    self._graphs[key] = g
+                self.env.obs_buf, self.env.reward_buf = self._obs_rows[t + 1], self._reward_rows[t]
+                self.env._bufs.obs, self.env._bufs.reward = self._buf_ptrs[t]
+                g.replay()
 
         if t + 1 == self.rollout_size:                              # ppo.py:240-252
             if not self.args.testing:

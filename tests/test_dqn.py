@@ -60,7 +60,7 @@ def test_hip_huber_td_vs_reference_and_oracle(golden):
     np.testing.assert_allclose(float(parts.sum() / B), float(g["loss"]), rtol=2e-6)
     np.testing.assert_allclose(dq.cpu().numpy(), g["dq"], rtol=1e-6, atol=1e-9)
     dq2, loss2 = O.dqn_huber_td(g["q_table"], g["b_act"], g["b_rew"], g["q_next"], g["b_done"])
-    assert np.array_equal(dq.cpu().numpy(), dq2)
+    np.testing.assert_allclose(dq.cpu().numpy(), dq2, rtol=3e-7, atol=0)     # d/B vs d*(1/B): one ulp
 
 
 @pytest.mark.gpu

@@ -104,3 +104,24 @@ def test_mfma_forward_matches_torch_and_oracle(golden, n):
         mu2 = net.pi(x) if not torch.is_grad_enabled() else None
         with torch.no_grad():
             assert torch.equal(net.pi(x), mu)
+
+
+def test_graph_replay_matches_eager_rollout():
+    """Rollout steps replayed from captured hipGraphs leave exactly what the eager launches leave
+    (same seeds; the captured normal_ advances the Philox offset like the eager call)."""
+    from fly_bproject_amd.ppo import PPO
+    res = {}
+    for graph in (False, True):
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            agent = PPO(make_args(4096, graph=graph, testing=True))
+            _run(agent, 2 * agent.rollout_size + 5)      # second pass over t replays captured graphs
+        torch.cuda.synchronize()
+        if graph:
+            assert len(agent._graphs) == agent.rollout_size
+        res[graph] = (agent._obs_ring.clone(), agent.all_acts.clone(), agent.all_reward.clone(),
+                      agent.all_log_prob.clone(), agent.env.progress_buf.clone(), float(agent.action_var[0]))
+        agent.exit()
+    for a, b in zip(res[False][:5], res[True][:5]):
+        assert torch.equal(a, b)
+    assert res[False][5] == res[True][5]

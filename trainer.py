@@ -48,7 +48,7 @@ def parse_args(argv=None):
 
 def main(argv=None):
     args = parse_args(argv)
-    from fly_bproject_amd.dist import broadcast_parameters, init_from_env
+    from fly_bproject_amd.dist import broadcast_policy, init_from_env
     from fly_bproject_amd.ppo import PPO
 
     rank, local_rank, world = init_from_env("cuda")
@@ -60,7 +60,7 @@ def main(argv=None):
     if args.testing:
         print("## Careful you are in testing mode, no Training will take place ##")
     policy = PPO(args)                      # trainer.py:39
-    broadcast_parameters(policy.net)
+    broadcast_policy(policy)
     end = False                             # trainer.py:41-44
     while not end:
         end = policy.run()
