@@ -196,6 +196,8 @@ def main():
     from fly_bproject_amd.ppo import PPO
 
     rank, local_rank, world = init_from_env("cuda")
+    if os.environ.get("FLY_SINGLE_GPU"):         # rehearsal of the N>1 path on a one-GPU box (gloo transport)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     torch.manual_seed(0)

@@ -37,7 +37,11 @@ __device__ __forceinline__ float elu(float x) { return x > 0.0f ? x : __expf(x) 
 // derivative of ELU expressed through its OUTPUT y: 1 for y > 0, y + 1 otherwise
 __device__ __forceinline__ float elu_grad_from_out(float y) { return y > 0.0f ? 1.0f : y + 1.0f; }
 
-// acc[t] += A[32 x K] * W[col tile t][K]^T for this wave's NT column tiles.
+// acc[t] (+)= W[col tile t][K] * A[32 rows x K]^T for this wave's NT column tiles.  The WEIGHTS are
+// the MFMA "A" operand and the activations the "B" operand, so the 32x32 result tile is
+// C[n][row]: a lane owns ONE row (lane&31) and, per group of four accumulator registers, FOUR
+// CONSECUTIVE output columns n = 8*(reg>>2) + 4*(lane>>5) + (reg&3) -- which makes the epilogue's
+// LDS traffic 16-byte vectors instead of scalars.
 //   lds_in : [32][K+4] floats (row-major, k contiguous)
 //   Wf     : this layer's weights in fragment order (mlp_layout.h): [col tile][K/8][64 lanes][4];
 //            `tile0` = first column tile of this wave.  One wave-instruction = one contiguous KiB.
@@ -51,49 +55,82 @@ __device__ __forceinline__ void tile_gemm(const float* __restrict__ Wf, int tile
     const float* bp[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) bp[t] = Wf + (long)(tile0 + t) * (K / 8) * 256 + lane * 4;
-    // operands of k-quad kq+1 (A from LDS, B from L2) are requested before the MFMAs of k-quad kq
-    float4 bnext[NT];
+    // B fragments (L2) are requested two k-quads ahead, A fragments (LDS) one k-quad ahead of the
+    // MFMAs that consume them.  The two-deep ring is two NAMED register sets walked in pairs (a
+    // runtime-indexed ring would live in scratch).
+    static_assert((K / 8) % 2 == 0, "k-quads are walked in pairs");
+    float4 b0[NT], b1[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) bnext[t] = *reinterpret_cast<const float4*>(bp[t]);
-    float4 anext = *reinterpret_cast<const float4*>(ap);
-#pragma unroll 4
-    for (int kq = 0; kq < K / 8; ++kq) {
-        float4 b[NT];
+    for (int t = 0; t < NT; ++t) {
+        b0[t] = *reinterpret_cast<const float4*>(bp[t]);
+        b1[t] = *reinterpret_cast<const float4*>(bp[t] + 256);
+    }
+    float4 a0 = *reinterpret_cast<const float4*>(ap);
+#pragma unroll 1
+    for (int kq = 0; kq < K / 8; kq += 2) {
+        // ---- k-quad kq: consume (a0, b0); request A of kq+1 and B of kq+2
+        float4 a1 = *reinterpret_cast<const float4*>(ap + 4 * (kq + 1));
+        float4 bu[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) b[t] = bnext[t];
-        const float4 a = anext;
-        if (kq + 1 < K / 8) {
+        for (int t = 0; t < NT; ++t) bu[t] = b0[t];
+        if (kq + 2 < K / 8) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) bnext[t] = *reinterpret_cast<const float4*>(bp[t] + 256 * (kq + 1));
-            anext = *reinterpret_cast<const float4*>(ap + 4 * (kq + 1));
+            for (int t = 0; t < NT; ++t) b0[t] = *reinterpret_cast<const float4*>(bp[t] + 256 * (kq + 2));
         }
-        __builtin_amdgcn_sched_barrier(0);              // keep the prefetch ahead of this k-quad's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bu[t].x, a0.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bu[t].y, a0.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bu[t].z, a0.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bu[t].w, a0.w, acc[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- k-quad kq+1: consume (a1, b1); request A of kq+2 and B of kq+3
+        if (kq + 2 < K / 8) a0 = *reinterpret_cast<const float4*>(ap + 4 * (kq + 2));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bu[t] = b1[t];
+        if (kq + 3 < K / 8) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) b1[t] = *reinterpret_cast<const float4*>(bp[t] + 256 * (kq + 3));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bu[t].x, a1.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bu[t].y, a1.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bu[t].z, a1.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bu[t].w, a1.w, acc[t], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-// C/D layout of the 32x32 tile: lane holds column (lane&31), rows (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// C/D layout of the 32x32 tile with the operand roles above: lane holds row (lane&31) and output
+// columns n = 8*g + 4*(lane>>5) + j for register 4*g + j.
+__device__ __forceinline__ int acc_n(int g, int lane) { return 8 * g + 4 * (lane >> 5); }
+// generic C/D map (A operand indexes rows): row (reg&3) + 8*(reg>>2) + 4*(lane>>5), column lane&31
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-// bias + ELU epilogue: writes the activation tile to LDS (the next layer's A operand).
+// bias + ELU epilogue: writes the activation tile to LDS (the next layer's operand), 16 bytes per store.
 template <int N, int NT>
 __device__ __forceinline__ void epilogue_elu(const f32x16 (&acc)[NT], const float* __restrict__ bias, int col0,
                                              float* lds_out, int lane)
 {
+    const int r = lane & 31;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int col = col0 + 32 * t + (lane & 31);
-        const float bv = bias[col];
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg)
-            lds_out[acc_row(reg, lane) * (N + 4) + col] = elu(acc[t][reg] + bv);
+        for (int g = 0; g < 4; ++g) {
+            const int nb = col0 + 32 * t + acc_n(g, lane);
+            const float4 bv = *reinterpret_cast<const float4*>(bias + nb);
+            float4 y;
+            y.x = elu(acc[t][4 * g + 0] + bv.x);
+            y.y = elu(acc[t][4 * g + 1] + bv.y);
+            y.z = elu(acc[t][4 * g + 2] + bv.z);
+            y.w = elu(acc[t][4 * g + 3] + bv.w);
+            *reinterpret_cast<float4*>(lds_out + r * (N + 4) + nb) = y;
+        }
     }
 }
 
@@ -103,8 +140,10 @@ template <int N>
 __device__ __forceinline__ void copy_tile_out(const float* lds_tile, float* __restrict__ dst, long row0, long nrows, int tid)
 {
     if (!dst) return;
+    static_assert((BM * N / 4) % THREADS == 0, "whole float4 rounds");
 #pragma unroll
-    for (int i = tid; i < BM * N / 4; i += THREADS) {
+    for (int u = 0; u < BM * N / 4 / THREADS; ++u) {
+        const int i = tid + u * THREADS;
         const int row = i / (N / 4), c4 = i - row * (N / 4);
         if (row0 + row < nrows)
             *reinterpret_cast<float4*>(dst + (row0 + row) * N + 4 * c4) =
@@ -124,91 +163,178 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NT])
 constexpr int LDS_A_FLOATS = BM * (MLP_H1 + 4);      // H1, later H3
 constexpr int LDS_B_FLOATS = BM * (MLP_H2 + 4);      // X0, later H2, later the split-K partials
 
+// In-kernel phase stamps (diagnostic instantiation only, tools/stamp_forward.py; the shipped
+// instantiation compiles them out): wave 0 / lane 0 of each workgroup stores s_memtime at the phase
+// boundaries into a buffer nothing else reads.
+template <bool STAMP>
+__device__ __forceinline__ void stamp(unsigned long long* buf, int slot)
+{
+    if (STAMP) {
+        if (threadIdx.x == 0) {
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+            buf[(long)blockIdx.x * 16 + slot] = t;
+        }
+    }
+}
+
 // x [n][73] -> out [n][32] (cols 0..17 = mean after ELU, col 18 = value, rest 0).
 // mu_out [n][18] / v_out [n] / h*_save are optional.
-__global__ __launch_bounds__(THREADS) void mlp_forward_kernel(
+// Persistent workgroups: the grid is at most 3 workgroups per CU and each walks tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ...; the NEXT tile's input rows are fetched into registers
+// (16-byte loads: a 32x73 tile is one contiguous, 16-byte aligned block) while the current tile
+// computes, so the ~5 us HBM round trip that used to open every workgroup is hidden.
+constexpr int XV = (BM * MLP_IN / 4 + THREADS - 1) / THREADS;       // float4 per thread for one x tile (584 / 256 -> 3)
+
+template <bool STAMP>
+__global__ __launch_bounds__(THREADS, 3) void mlp_forward_kernel(
     const float* __restrict__ P, const float* __restrict__ PF, const float* __restrict__ x, long n,
     float* __restrict__ mu_out, float* __restrict__ v_out, float* __restrict__ out_save,
-    float* __restrict__ h1_save, float* __restrict__ h2_save, float* __restrict__ h3_save)
+    float* __restrict__ h1_save, float* __restrict__ h2_save, float* __restrict__ h3_save,
+    unsigned long long* __restrict__ stamps)
 {
     __shared__ __attribute__((aligned(16))) float lds[LDS_A_FLOATS + LDS_B_FLOATS];
     float* ldsA = lds;
     float* ldsB = lds + LDS_A_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long row0 = (long)blockIdx.x * BM;
+    const long ntiles = (n + BM - 1) / BM;
+    const long total = n * MLP_IN;
 
-    // stage the 32 x 73 input tile (contiguous in HBM) as [32][80+4], zero padded
-    for (int i = tid; i < BM * (MLP_IN_PAD + 4); i += THREADS) ldsB[i] = 0.0f;
-    __syncthreads();
-    {
-        const long base = row0 * MLP_IN;
-        const long lim = n * MLP_IN;
-        for (int i = tid; i < BM * MLP_IN; i += THREADS) {
-            const int rr = i / MLP_IN, cc = i - rr * MLP_IN;
-            if (base + i < lim) ldsB[rr * (MLP_IN_PAD + 4) + cc] = x[base + i];
+    float4 xr[XV];
+    auto x_load = [&](long tile) {
+        const long base = tile * (BM * MLP_IN);
+#pragma unroll
+        for (int u = 0; u < XV; ++u) {
+            const long f = base + 4L * (tid + u * THREADS);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tid + u * THREADS < BM * MLP_IN / 4) {
+                if (f + 3 < total) v = *reinterpret_cast<const float4*>(x + f);
+                else {
+                    if (f < total) v.x = x[f];
+                    if (f + 1 < total) v.y = x[f + 1];
+                    if (f + 2 < total) v.z = x[f + 2];
+                }
+            }
+            xr[u] = v;
         }
-    }
-    __syncthreads();
+    };
+    auto x_store = [&](int tid) {   // registers -> ldsB as [32][80+4]; pad columns 73..79 zeroed
+#pragma unroll
+        for (int u = 0; u < XV; ++u) {
+            const int i4 = tid + u * THREADS;
+            if (i4 < BM * MLP_IN / 4) {
+                const float e[4] = {xr[u].x, xr[u].y, xr[u].z, xr[u].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int f = 4 * i4 + j;
+                    const int rr = f / MLP_IN, cc = f - rr * MLP_IN;
+                    ldsB[rr * (MLP_IN_PAD + 4) + cc] = e[j];
+                }
+            }
+        }
+        if (tid < BM * (MLP_IN_PAD - MLP_IN)) {
+            const int rr = tid / (MLP_IN_PAD - MLP_IN), cc = MLP_IN + tid - rr * (MLP_IN_PAD - MLP_IN);
+            ldsB[rr * (MLP_IN_PAD + 4) + cc] = 0.0f;
+        }
+    };
 
-    {   // L1: 80 -> 256, wave owns 64 columns
-        f32x16 acc[2];
-        zero_acc(acc);
-        tile_gemm<MLP_IN_PAD, 2>(PF + MLP_OFF_F1, wave * 2, ldsB, acc, lane);
-        epilogue_elu<MLP_H1, 2>(acc, P + MLP_OFF_B1, wave * 64, ldsA, lane);
-    }
-    __syncthreads();
-    copy_tile_out<MLP_H1>(ldsA, h1_save, row0, n, tid);
-    {   // L2: 256 -> 128, wave owns 32 columns
-        f32x16 acc[1];
-        zero_acc(acc);
-        tile_gemm<MLP_H1, 1>(PF + MLP_OFF_F2, wave, ldsA, acc, lane);
-        epilogue_elu<MLP_H2, 1>(acc, P + MLP_OFF_B2, wave * 32, ldsB, lane);
-    }
-    __syncthreads();
-    copy_tile_out<MLP_H2>(ldsB, h2_save, row0, n, tid);
-    {   // L3: 128 -> 128 (actor | critic heads stacked)
-        f32x16 acc[1];
-        zero_acc(acc);
-        tile_gemm<MLP_H2, 1>(PF + MLP_OFF_F3, wave, ldsB, acc, lane);
-        epilogue_elu<MLP_H3, 1>(acc, P + MLP_OFF_B3, wave * 32, ldsA, lane);
-    }
-    __syncthreads();
-    copy_tile_out<MLP_H3>(ldsA, h3_save, row0, n, tid);
-    {   // L4: 128 -> 32, split-K over the four waves (32 k each), partials reduced through LDS
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-        const int r = lane & 31, h = lane >> 5;
-        const float* ap = ldsA + r * (MLP_H3 + 4) + wave * 32 + h * 16;
-        const float* bp = PF + MLP_OFF_F4 + (wave * 4) * 256 + lane * 4;    // [wave][kq][lane][4]
-#pragma unroll
-        for (int kq = 0; kq < 4; ++kq) {
-            const float4 a = *reinterpret_cast<const float4*>(ap + 4 * kq);
-            const float4 b = *reinterpret_cast<const float4*>(bp + 256 * kq);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    long tile = blockIdx.x;
+    if (tile < ntiles) x_load(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const long row0 = tile * BM;
+        // opaque per-iteration copy of the thread index: keeps the dozens of tile-invariant LDS/global
+        // offsets from being hoisted out of the tile loop (they would all be live across it and spill)
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
+        stamp<STAMP>(stamps, 0);
+        if (STAMP && threadIdx.x == 0) {
+            unsigned long long t;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+            stamps[(long)blockIdx.x * 16 + 14] = t;
         }
-        float* part = ldsB + wave * (BM * MLP_OUT);
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) part[acc_row(reg, lane) * MLP_OUT + r] = acc[reg];
-    }
-    __syncthreads();
-    for (int i = tid; i < BM * MLP_OUT; i += THREADS) {
-        const int row = i / MLP_OUT, col = i - row * MLP_OUT;
-        float z = ((ldsB[i] + ldsB[BM * MLP_OUT + i]) + ldsB[2 * BM * MLP_OUT + i]) + ldsB[3 * BM * MLP_OUT + i];
-        z += P[MLP_OFF_B4 + col];
-        float y = (col < MLP_NACT) ? elu(z) : ((col == MLP_NACT) ? z : 0.0f);   // ELU on the mean (ppo.py:30), none on v
-        const long grow = row0 + row;
-        if (grow < n) {
-            if (out_save) out_save[grow * MLP_OUT + col] = y;
-            if (mu_out && col < MLP_NACT) mu_out[grow * MLP_NACT + col] = y;
-            if (v_out && col == MLP_NACT) v_out[grow] = y;
+        x_store(tl);
+        __syncthreads();
+        if (tile + gridDim.x < ntiles) x_load(tile + gridDim.x);     // lands during this tile's MFMAs
+        stamp<STAMP>(stamps, 1);
+        {   // L1: 80 -> 256, wave owns 64 columns
+            f32x16 acc[2];
+            zero_acc(acc);
+            tile_gemm<MLP_IN_PAD, 2>(PF + MLP_OFF_F1, wave * 2, ldsB, acc, lane);
+            stamp<STAMP>(stamps, 2);
+            epilogue_elu<MLP_H1, 2>(acc, P + MLP_OFF_B1, wave * 64, ldsA, lane);
         }
+        stamp<STAMP>(stamps, 3);
+        __syncthreads();
+        stamp<STAMP>(stamps, 4);
+        copy_tile_out<MLP_H1>(ldsA, h1_save, row0, n, tl);
+        stamp<STAMP>(stamps, 5);
+        {   // L2: 256 -> 128, wave owns 32 columns
+            f32x16 acc[1];
+            zero_acc(acc);
+            tile_gemm<MLP_H1, 1>(PF + MLP_OFF_F2, wave, ldsA, acc, lane);
+            stamp<STAMP>(stamps, 6);
+            epilogue_elu<MLP_H2, 1>(acc, P + MLP_OFF_B2, wave * 32, ldsB, lane);
+        }
+        stamp<STAMP>(stamps, 7);
+        __syncthreads();
+        stamp<STAMP>(stamps, 8);
+        copy_tile_out<MLP_H2>(ldsB, h2_save, row0, n, tl);
+        {   // L3: 128 -> 128 (actor | critic heads stacked)
+            f32x16 acc[1];
+            zero_acc(acc);
+            stamp<STAMP>(stamps, 9);
+            tile_gemm<MLP_H2, 1>(PF + MLP_OFF_F3, wave, ldsB, acc, lane);
+            stamp<STAMP>(stamps, 10);
+            epilogue_elu<MLP_H3, 1>(acc, P + MLP_OFF_B3, wave * 32, ldsA, lane);
+        }
+        stamp<STAMP>(stamps, 11);
+        __syncthreads();
+        stamp<STAMP>(stamps, 12);
+        copy_tile_out<MLP_H3>(ldsA, h3_save, row0, n, tl);
+        {   // L4: 128 -> 32, split-K over the four waves (32 k each), partials reduced through LDS
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+            const int r = lane & 31, h = lane >> 5;
+            const float* ap = ldsA + r * (MLP_H3 + 4) + wave * 32 + h * 16;
+            const float* bp = PF + MLP_OFF_F4 + (wave * 4) * 256 + lane * 4;    // [wave][kq][lane][4]
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                const float4 a = *reinterpret_cast<const float4*>(ap + 4 * kq);
+                const float4 b = *reinterpret_cast<const float4*>(bp + 256 * kq);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc, 0, 0, 0);
+            }
+            float* part = ldsB + wave * (BM * MLP_OUT);                          // [row][32]
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(part + r * MLP_OUT + acc_n(g, lane)) =
+                    make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        }
+        __syncthreads();
+        for (int i = tl; i < BM * MLP_OUT; i += THREADS) {
+            const int row = i >> 5, col = i & 31;
+            float z = ((ldsB[i] + ldsB[BM * MLP_OUT + i]) + ldsB[2 * BM * MLP_OUT + i]) + ldsB[3 * BM * MLP_OUT + i];
+            z += P[MLP_OFF_B4 + col];
+            float y = (col < MLP_NACT) ? elu(z) : ((col == MLP_NACT) ? z : 0.0f);   // ELU on the mean (ppo.py:30), none on v
+            const long grow = row0 + row;
+            if (grow < n) {
+                if (out_save) out_save[grow * MLP_OUT + col] = y;
+                if (mu_out && col < MLP_NACT) mu_out[grow * MLP_NACT + col] = y;
+                if (v_out && col == MLP_NACT) v_out[grow] = y;
+            }
+        }
+        stamp<STAMP>(stamps, 13);
+        if (STAMP && threadIdx.x == 0) {
+            unsigned long long t;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+            stamps[(long)blockIdx.x * 16 + 15] = t;
+        }
+        __syncthreads();            // ldsB (partials) is the next tile's input buffer
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // Backward, part 1: PPO loss gradient at the network outputs + the dX chain (ppo.py:184-197).
@@ -220,14 +346,20 @@ __global__ __launch_bounds__(THREADS) void mlp_forward_kernel(
 //   dz4 [n][32]: cols 0..17 d/d(pre-ELU mean), col 18 d/d(value), rest 0
 //   dz3 [n][128], dz2 [n][128], dz1 [n][256]: gradients at the pre-activations of layers 3,2,1
 //   loss_part [grid][2]: per-workgroup sums of the policy term and of the Huber term
-// dZ = dA * ELU'(H), in place on the LDS tile that holds H (pitch N+4): the lane that owns an
-// accumulator element reads H there and overwrites it with dZ.
-__device__ __forceinline__ void epilogue_dact_inplace(const f32x16& acc, int col, int N, float* lds_tile, int lane)
+// dZ = dA * ELU'(H), in place on the LDS tile that holds H (pitch N+4): the lane that owns four
+// consecutive accumulator columns of its row reads H there as one float4 and overwrites it with dZ.
+__device__ __forceinline__ void epilogue_dact_inplace(const f32x16& acc, int col0, int N, float* lds_tile, int lane)
 {
+    const int r = lane & 31;
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        float* p = lds_tile + acc_row(reg, lane) * (N + 4) + col;
-        *p = acc[reg] * elu_grad_from_out(*p);
+    for (int g = 0; g < 4; ++g) {
+        float4* p = reinterpret_cast<float4*>(lds_tile + r * (N + 4) + col0 + acc_n(g, lane));
+        float4 hv = *p;
+        hv.x = acc[4 * g + 0] * elu_grad_from_out(hv.x);
+        hv.y = acc[4 * g + 1] * elu_grad_from_out(hv.y);
+        hv.z = acc[4 * g + 2] * elu_grad_from_out(hv.z);
+        hv.w = acc[4 * g + 3] * elu_grad_from_out(hv.w);
+        *p = hv;
     }
 }
 
@@ -264,7 +396,7 @@ constexpr int BW_Z4 = BW_Z3 + BM * (MLP_H3 + 4);           // [32][36]
 constexpr int BW_Z1 = BW_Z3;                               // [32][260] aliases Z3|Z4|tail once they are dead
 constexpr int BW_FLOATS = BW_Z1 + BM * (MLP_H1 + 4) + BM + 8;
 
-__global__ __launch_bounds__(THREADS) void mlp_backward_dx_kernel(
+__global__ __launch_bounds__(THREADS, 3) void mlp_backward_dx_kernel(
     const float* __restrict__ PT, const float* __restrict__ out_saved, const float* __restrict__ h1_saved,
     const float* __restrict__ h2_saved, const float* __restrict__ h3_saved,
     const float* __restrict__ action, const float* __restrict__ old_logp, const float* __restrict__ adv,
@@ -345,7 +477,7 @@ __global__ __launch_bounds__(THREADS) void mlp_backward_dx_kernel(
         f32x16 acc[1];
         zero_acc(acc);
         tile_gemm<MLP_OUT, 1>(PT + MLP_OFF_TF4, wave, ldsZ4, acc, lane);
-        epilogue_dact_inplace(acc[0], wave * 32 + (lane & 31), MLP_H3, ldsZ3, lane);
+        epilogue_dact_inplace(acc[0], wave * 32, MLP_H3, ldsZ3, lane);
     }
     tile_store_lds<MLP_H2>(h2r, ldsZ2, tid);
     __syncthreads();
@@ -354,7 +486,7 @@ __global__ __launch_bounds__(THREADS) void mlp_backward_dx_kernel(
         f32x16 acc[1];
         zero_acc(acc);
         tile_gemm<MLP_H3, 1>(PT + MLP_OFF_TF3, wave, ldsZ3, acc, lane);
-        epilogue_dact_inplace(acc[0], wave * 32 + (lane & 31), MLP_H2, ldsZ2, lane);
+        epilogue_dact_inplace(acc[0], wave * 32, MLP_H2, ldsZ2, lane);
     }
     __syncthreads();                                       // Z3 / Z4 are dead from here: Z1 may overwrite them
     copy_tile_out<MLP_H2>(ldsZ2, dz2, row0, n, tid);
@@ -366,8 +498,8 @@ __global__ __launch_bounds__(THREADS) void mlp_backward_dx_kernel(
         tile_gemm<MLP_H2, 2>(PT + MLP_OFF_TF2, wave * 2, ldsZ2, acc, lane);
         tile_store_lds<MLP_H1>(h1r, ldsZ1, tid);
         __syncthreads();
-        epilogue_dact_inplace(acc[0], wave * 64 + (lane & 31), MLP_H1, ldsZ1, lane);
-        epilogue_dact_inplace(acc[1], wave * 64 + 32 + (lane & 31), MLP_H1, ldsZ1, lane);
+        epilogue_dact_inplace(acc[0], wave * 64, MLP_H1, ldsZ1, lane);
+        epilogue_dact_inplace(acc[1], wave * 64 + 32, MLP_H1, ldsZ1, lane);
     }
     __syncthreads();
     copy_tile_out<MLP_H1>(ldsZ1, dz1, row0, n, tid);
@@ -700,10 +832,27 @@ extern "C" hipError_t flyhip_launch_mlp_forward(const float* P, const float* PF,
                                                 float* v_out, float* out_save, float* h1_save, float* h2_save,
                                                 float* h3_save, void* stream)
 {
-    const int grid = (int)((n + BM - 1) / BM);
-    hipLaunchKernelGGL(mlp_forward_kernel, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PF, x, (long)n,
-                       mu_out, v_out, out_save, h1_save, h2_save, h3_save);
+    // Large inputs (the critic pass over the whole rollout) run persistent workgroups, 3 per CU, each
+    // walking many tiles with the next tile's rows prefetched.  Up to a few tiles per slot the
+    // hardware's dynamic workgroup dispatch balances better than a fixed walk (1280 tiles over 768
+    // slots would leave a third of the chip idle for the second half), so those launch one tile each.
+    const long tiles = (n + BM - 1) / BM;
+    const int grid = (int)(tiles <= 4 * 768 ? tiles : 768);
+    hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PF, x, (long)n,
+                       mu_out, v_out, out_save, h1_save, h2_save, h3_save, (unsigned long long*)nullptr);
     return hipGetLastError();
+}
+
+// diagnostic build of the same kernel with phase stamps (tools/stamp_forward.py); not part of the ABI header
+extern "C" int flyhip_debug_mlp_forward_stamped(const float* P, const float* PF, const float* x, int64_t n,
+                                                float* out_save, float* h1_save, float* h2_save, float* h3_save,
+                                                unsigned long long* stamps, void* stream)
+{
+    const long tiles = (n + BM - 1) / BM;
+    const int grid = (int)(tiles <= 4 * 768 ? tiles : 768);
+    hipLaunchKernelGGL(mlp_forward_kernel<true>, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PF, x, (long)n,
+                       (float*)nullptr, (float*)nullptr, out_save, h1_save, h2_save, h3_save, stamps);
+    return (int)hipGetLastError();
 }
 
 extern "C" hipError_t flyhip_launch_mlp_backward_dx(const float* PT, const float* out_saved, const float* h1,

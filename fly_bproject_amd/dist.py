@@ -45,6 +45,8 @@ def init_from_env(device_type="cuda"):
     """Read RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* (torch.distributed.run) and join the group."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("FLY_SINGLE_GPU"):          # rehearse N ranks on one GPU (tests; needs FLY_DIST_BACKEND=gloo)
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Where does a workgroup of mlp_forward_kernel spend its cycles?  Runs the stamped diagnostic
+instantiation at the update size (40960 rows) and prints the mean cycles per phase (wave 0)."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from fly_bproject_amd import _lib  # noqa: E402
+from fly_bproject_amd.policy import PackedPolicy  # noqa: E402
+from fly_bproject_amd.ppo import Net  # noqa: E402
+
+rows = int(os.environ.get("ROWS", "40960"))
+lib = _lib.load()
+net = Net(73, 18).to("cuda:0")
+pol = PackedPolicy(net, "cuda:0")
+pol.init_training(rows)
+x = torch.randn(rows, 73, device="cuda:0")
+grid = (rows + 31) // 32
+stamps = torch.zeros(grid * 16, dtype=torch.int64, device="cuda:0")
+p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+s = pol.saves
+fn = lib.flyhip_debug_mlp_forward_stamped
+fn.argtypes = [C.c_void_p] * 3 + [C.c_int64] + [C.c_void_p] * 6
+for _ in range(3):
+    fn(p(pol.P), p(pol.PF), p(x), rows, p(s["out"]), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(stamps), None)
+torch.cuda.synchronize()
+raw = stamps.cpu().numpy().reshape(grid, 16).astype(np.int64)
+raw = raw[raw[:, 13] > 0]                      # workgroups that stamped (persistent grids are smaller)
+grid = raw.shape[0]
+st = raw[:, :14]
+real = (raw[:, 15] - raw[:, 14]).astype(np.float64)          # 100 MHz ticks
+clk = (st[:, 13] - st[:, 0]) / np.maximum(real, 1) * 100e6
+print("in-kernel clock (s_memtime / s_memrealtime): median %.3f GHz, p10 %.3f, p90 %.3f" %
+      (np.median(clk) / 1e9, np.percentile(clk, 10) / 1e9, np.percentile(clk, 90) / 1e9))
+d = np.diff(st, axis=1)
+names = ["x stage+barrier", "L1 gemm", "L1 epilogue", "L1 barrier", "copy H1", "L2 gemm", "L2 epilogue", "L2 barrier",
+         "copy H2", "L3 gemm", "L3 epilogue", "L3 barrier", "copy H3 + L4 + out"]
+tot = (st[:, 13] - st[:, 0])
+print("workgroups", grid, "mean total cycles per WG (s_memtime ticks = shader cycles)", tot.mean(), "median", np.median(tot))
+for i, nm in enumerate(names):
+    print("%-22s mean %8.0f  median %8.0f  (%4.1f %%)" % (nm, d[:, i].mean(), np.median(d[:, i]), 100 * d[:, i].mean() / tot.mean()))
+rt = raw[:, 15].max() - raw[:, 14].min()
+print("first start -> last end (s_memrealtime, global): %.2f us" % (rt / 100.0))
