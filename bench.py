@@ -130,6 +130,26 @@ def kernel_rooflines(num_envs, T, reps):
         mfma("mlp_grad_w_kernel (+reduce)", t_gw, MLP_GRAD_W_FLOP * rows, 75),
         hbm("mlp_adam_kernel", t_adam, 74272 * 4 * 7, 75),
     ]
+    # HBM bytes per launch from the committed PMC passes (profiles/*_traffic.json, produced by
+    # tools/summarize_pmc.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of the same kernels)
+    traffic = {}
+    try:
+        import glob
+        files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_traffic.json")))
+        if files:
+            traffic = json.load(open(files[-1]))
+    except Exception:
+        traffic = {}
+    grids = {"fly_kernel<63> (fly_step)": ("fly_kernel<63>", ((num_envs + 15) // 16) * 256),
+             "mlp_forward_kernel": ("mlp_forward_kernel", ((rows + 31) // 32) * 256),
+             "mlp_backward_dx_kernel": ("mlp_backward_dx_kernel", ((rows + 31) // 32) * 256),
+             "mlp_grad_w_kernel (+reduce)": ("mlp_grad_w_kernel", 256 * 512)}
+    for k in ks:
+        key = grids.get(k["kernel"])
+        if key:
+            t = traffic.get("%s@%d" % key)
+            if t:
+                k["traffic"] = t["hbm_bytes_per_launch"]
     ks.sort(key=lambda k: -k["iteration_share_ms"])
     return ks
 

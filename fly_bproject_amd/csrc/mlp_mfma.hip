@@ -394,7 +394,7 @@ constexpr int BW_Z2 = 0;                                   // [32][132]
 constexpr int BW_Z3 = BW_Z2 + BM * (MLP_H2 + 4);           // [32][132]
 constexpr int BW_Z4 = BW_Z3 + BM * (MLP_H3 + 4);           // [32][36]
 constexpr int BW_Z1 = BW_Z3;                               // [32][260] aliases Z3|Z4|tail once they are dead
-constexpr int BW_FLOATS = BW_Z1 + BM * (MLP_H1 + 4) + BM + 8;
+constexpr int BW_FLOATS = BW_Z1 + BM * (MLP_H1 + 4) + BM + 8 + 24;
 
 __global__ __launch_bounds__(THREADS, 3) void mlp_backward_dx_kernel(
     const float* __restrict__ PT, const float* __restrict__ out_saved, const float* __restrict__ h1_saved,
@@ -417,18 +417,26 @@ __global__ __launch_bounds__(THREADS, 3) void mlp_backward_dx_kernel(
     TileRegs<MLP_H3> h3r;
     tile_load<MLP_H3>(h3r, h3_saved, row0, n, tid);       // in flight during the loss phase
 
+    // per-action constants of the diagonal Gaussian, once per workgroup: 1/L_j and sum log L_j
+    float* invL = red + 2;                                 // [18] (+1: half_log_det)
+    if (tid >= 64 && tid < 64 + MLP_NACT) invL[tid - 64] = 1.0f / sqrtf(var[tid - 64]);
+    if (tid == 96) {
+        float hl = 0.0f;
+        for (int j = 0; j < MLP_NACT; ++j) hl += logf(sqrtf(var[j]));
+        invL[MLP_NACT] = hl;
+    }
+    __syncthreads();
     // per-row loss terms (one lane per row)
     if (tid < BM) {
         const long g = row0 + tid;
         float c = 0.0f, pol = 0.0f, hub = 0.0f;
         if (g < n) {
-            float M = 0.0f, half_log_det = 0.0f;
+            float M = 0.0f;
+            const float half_log_det = invL[MLP_NACT];
 #pragma unroll
             for (int j = 0; j < MLP_NACT; ++j) {
-                const float L = sqrtf(var[j]);
-                const float xj = (action[g * MLP_NACT + j] - out_saved[g * MLP_OUT + j]) / L;
+                const float xj = (action[g * MLP_NACT + j] - out_saved[g * MLP_OUT + j]) * invL[j];
                 M += xj * xj;
-                half_log_det += logf(L);
             }
             const float logp = -0.5f * (33.08178959434617f + M) - half_log_det;
             const float ratio = expf(logp - old_logp[g]);

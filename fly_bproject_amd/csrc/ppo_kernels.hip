@@ -88,19 +88,32 @@ __global__ __launch_bounds__(256) void ppo_td_gae_kernel(
 // ppo.py:233 + :237 in one tiny launch: score += mean(reward)/num_eval_freq (kept on the device:
 // the reference's per-step .item() host sync is gone) and action_var = max(var_min, var - decay).
 // One workgroup, fixed reduction order: deterministic.
-__global__ __launch_bounds__(256) void ppo_bookkeeping_kernel(const float* __restrict__ reward, long n,
-                                                              float* __restrict__ score_acc, float score_scale,
-                                                              float* __restrict__ action_var, int nvar,
-                                                              float var_decay, float var_min)
+__global__ __launch_bounds__(1024) void ppo_bookkeeping_kernel(const float* __restrict__ reward, long n,
+                                                               float* __restrict__ score_acc, float score_scale,
+                                                               float* __restrict__ action_var, int nvar,
+                                                               float var_decay, float var_min)
 {
-    __shared__ float red[4];
+    __shared__ float red[16];
     const int tid = threadIdx.x;
+    // 16-byte loads, all of a thread's loads in flight at once (n = 8192 -> two float4 per thread)
     float s = 0.0f;
-    for (long i = tid; i < n; i += 256) s += reward[i];
+    const long n4 = n >> 2;
+    const float4* r4 = reinterpret_cast<const float4*>(reward);
+    const bool aligned = (reinterpret_cast<uintptr_t>(reward) & 15) == 0;
+    if (aligned) {
+        for (long i = tid; i < n4; i += 1024) { const float4 v = r4[i]; s += (v.x + v.y) + (v.z + v.w); }
+        for (long i = 4 * n4 + tid; i < n; i += 1024) s += reward[i];
+    } else {
+        for (long i = tid; i < n; i += 1024) s += reward[i];
+    }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
-    if (tid == 0) *score_acc += (((red[0] + red[1]) + red[2]) + red[3]) / (float)n * score_scale;
+    if (tid == 0) {
+        float t = 0.0f;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        *score_acc += t / (float)n * score_scale;
+    }
     if (tid < nvar && var_decay > 0.0f) action_var[tid] = fmaxf(var_min, action_var[tid] - var_decay);
 }
 
@@ -110,7 +123,7 @@ extern "C" hipError_t flyhip_launch_bookkeeping(const float* reward, int64_t n, 
                                                 float* action_var, int nvar, float var_decay, float var_min,
                                                 void* stream)
 {
-    hipLaunchKernelGGL(ppo_bookkeeping_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, reward, (long)n, score_acc,
+    hipLaunchKernelGGL(ppo_bookkeeping_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, reward, (long)n, score_acc,
                        score_scale, action_var, nvar, var_decay, var_min);
     return hipGetLastError();
 }
