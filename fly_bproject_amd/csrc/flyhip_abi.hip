@@ -45,6 +45,10 @@ extern "C" hipError_t flyhip_launch_dqn_huber_td(const float* q_table, const flo
                                                  const float* q_next, const float* done, float discount, int A, int64_t B,
                                                  float* dq, float* loss_part, void* stream);
 
+extern "C" hipError_t flyhip_launch_mlp_forward_sample(const float* P, const float* PF, const float* x, int64_t n,
+                                                       const float* eps, const float* var, float* act_out,
+                                                       float* logp_out, float* mu_out, void* stream);
+
 struct FlyEnv {
     FlyConfig host;
     FlyConfig* dev;
@@ -200,6 +204,18 @@ int mlp_forward(const float* params, const float* params_frag, const float* x, i
     if (((uintptr_t)params_frag & 15)) return fail(FLY_E_ARG, "mlp_forward: params_frag must be 16-byte aligned");
     hipError_t e = flyhip_launch_mlp_forward(params, params_frag, x, n, mu_out, v_out, out_save, h1_save, h2_save, h3_save, stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_forward launch");
+    return FLY_OK;
+}
+
+int mlp_forward_sample(const float* params, const float* params_frag, const float* x, int64_t n,
+                       const float* eps, const float* var, float* act_out, float* logp_out,
+                       float* mu_out, void* stream)
+{
+    if (!params || !params_frag || !x || !eps || !var || !act_out || !logp_out)
+        return fail(FLY_E_ARG, "mlp_forward_sample: null pointer");
+    if (n <= 0) return fail(FLY_E_ARG, "mlp_forward_sample: n must be > 0");
+    hipError_t e = flyhip_launch_mlp_forward_sample(params, params_frag, x, n, eps, var, act_out, logp_out, mu_out, stream);
+    if (e != hipSuccess) return hip_fail(e, "mlp_forward_sample launch");
     return FLY_OK;
 }
 

@@ -191,7 +191,8 @@ __global__ __launch_bounds__(THREADS, 3) void mlp_forward_kernel(
     const float* __restrict__ P, const float* __restrict__ PF, const float* __restrict__ x, long n,
     float* __restrict__ mu_out, float* __restrict__ v_out, float* __restrict__ out_save,
     float* __restrict__ h1_save, float* __restrict__ h2_save, float* __restrict__ h3_save,
-    unsigned long long* __restrict__ stamps)
+    const float* __restrict__ smp_eps, const float* __restrict__ smp_var, float* __restrict__ smp_act,
+    float* __restrict__ smp_logp, unsigned long long* __restrict__ stamps)
 {
     __shared__ __attribute__((aligned(16))) float lds[LDS_A_FLOATS + LDS_B_FLOATS];
     float* ldsA = lds;
@@ -324,6 +325,24 @@ __global__ __launch_bounds__(THREADS, 3) void mlp_forward_kernel(
                 if (out_save) out_save[grow * MLP_OUT + col] = y;
                 if (mu_out && col < MLP_NACT) mu_out[grow * MLP_NACT + col] = y;
                 if (v_out && col == MLP_NACT) v_out[grow] = y;
+            }
+            if (smp_eps) {
+                // ppo.py:215-220 fused: the 32 lanes that hold one output row sample its action
+                // (a = mu + sqrt(var) eps), reduce the Mahalanobis term and sum log L with a fixed
+                // xor-butterfly over the half-wave, and write the clipped action and the log-prob.
+                float x2 = 0.0f, lg = 0.0f, a = 0.0f;
+                const bool on = (col < MLP_NACT) && (grow < n);
+                if (on) {
+                    const float L = sqrtf(smp_var[col]);
+                    a = y + L * smp_eps[grow * MLP_NACT + col];
+                    const float xj = (a - y) / L;
+                    x2 = xj * xj;
+                    lg = logf(L);
+                }
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) { x2 += __shfl_xor(x2, o, 32); lg += __shfl_xor(lg, o, 32); }
+                if (on) smp_act[grow * MLP_NACT + col] = fminf(fmaxf(a, -1.0f), 1.0f);
+                if (col == 0 && grow < n) smp_logp[grow] = -0.5f * (33.08178959434617f + x2) - lg;
             }
         }
         stamp<STAMP>(stamps, 13);
@@ -847,7 +866,20 @@ extern "C" hipError_t flyhip_launch_mlp_forward(const float* P, const float* PF,
     const long tiles = (n + BM - 1) / BM;
     const int grid = (int)(tiles <= 4 * 768 ? tiles : 768);
     hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PF, x, (long)n,
-                       mu_out, v_out, out_save, h1_save, h2_save, h3_save, (unsigned long long*)nullptr);
+                       mu_out, v_out, out_save, h1_save, h2_save, h3_save, (const float*)nullptr, (const float*)nullptr,
+                       (float*)nullptr, (float*)nullptr, (unsigned long long*)nullptr);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t flyhip_launch_mlp_forward_sample(const float* P, const float* PF, const float* x, int64_t n,
+                                                       const float* eps, const float* var, float* act_out,
+                                                       float* logp_out, float* mu_out, void* stream)
+{
+    const long tiles = (n + BM - 1) / BM;
+    const int grid = (int)(tiles <= 4 * 768 ? tiles : 768);
+    hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PF, x, (long)n,
+                       mu_out, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, eps,
+                       var, act_out, logp_out, (unsigned long long*)nullptr);
     return hipGetLastError();
 }
 
@@ -859,7 +891,8 @@ extern "C" int flyhip_debug_mlp_forward_stamped(const float* P, const float* PF,
     const long tiles = (n + BM - 1) / BM;
     const int grid = (int)(tiles <= 4 * 768 ? tiles : 768);
     hipLaunchKernelGGL(mlp_forward_kernel<true>, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PF, x, (long)n,
-                       (float*)nullptr, (float*)nullptr, out_save, h1_save, h2_save, h3_save, stamps);
+                       (float*)nullptr, (float*)nullptr, out_save, h1_save, h2_save, h3_save, (const float*)nullptr,
+                       (const float*)nullptr, (float*)nullptr, (float*)nullptr, stamps);
     return (int)hipGetLastError();
 }
 
@@ -878,7 +911,7 @@ extern "C" hipError_t flyhip_launch_mlp_backward_dx(const float* PT, const float
 }
 
 // workgroups per layer, proportional to the layer's share of the dW FLOPs (256 in total)
-static const int kGradWgs[4] = {72, 112, 56, 16};
+static const int kGradWgs[4] = {68, 120, 52, 16};
 
 extern "C" int64_t flyhip_mlp_grad_workspace_floats(void)
 {

@@ -236,9 +236,9 @@ class PPO:
         fwd, smp, book, bufs = [], [], [], []
         for t in range(T):
             fwd.append((P(pol.P.data_ptr()), P(pol.PF.data_ptr()), P(self._obs_rows[t].data_ptr()), C.c_int64(n),
-                        P(self._mu.data_ptr()), None, None, None, None, None))
-            smp.append((P(self._mu.data_ptr()), P(self.action_var.data_ptr()), P(self._eps_all[t].data_ptr()),
-                        P(self._act_rows[t].data_ptr()), P(self.all_log_prob[t].data_ptr()), C.c_int64(n)))
+                        P(self._eps_all[t].data_ptr()), P(self.action_var.data_ptr()), P(self._act_rows[t].data_ptr()),
+                        P(self.all_log_prob[t].data_ptr()), None))
+            smp.append(None)
             book.append((P(self._reward_rows[t].data_ptr()), C.c_int64(n), P(self._score_acc.data_ptr()),
                          C.c_float(1.0 / self.num_eval_freq), P(self.action_var.data_ptr()), C.c_int(self.num_acts)))
             bufs.append((self._obs_rows[t + 1].data_ptr(), self._reward_rows[t].data_ptr()))
@@ -246,14 +246,13 @@ class PPO:
         self._var_min = C.c_float(0.01)
 
     def _launch_step(self, t):
-        """The device work of one env step (ppo.py:213-237): four launches, no host logic.  Rows of
+        """The device work of one env step (ppo.py:213-237): three launches, no host logic.  Rows of
         the rollout are written in place (obs row t+1, action/log-prob/reward rows t)."""
         lib, env = self._lib, self.env
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         if t == 0:
             self._eps_all.normal_(generator=self._gen)              # the eps of MultivariateNormal.sample, whole rollout
-        rc = lib.mlp_forward(*self._fwd_args[t], st)                # ppo.py:214
-        rc |= lib.ppo_sample_logprob(*self._smp_args[t], st)        # ppo.py:215-220, :227
+        rc = lib.mlp_forward_sample(*self._fwd_args[t], st)         # ppo.py:214-220, :227 (policy + sampling fused)
         env.obs_buf, env.reward_buf = self._obs_rows[t + 1], self._reward_rows[t]      # ppo.py:228-229
         env._bufs.obs, env._bufs.reward = self._buf_ptrs[t]
         rc |= lib.fly_step(env._handle, C.c_void_p(self._act_rows[t].data_ptr()), C.byref(env._bufs), st)  # ppo.py:223

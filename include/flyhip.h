@@ -185,6 +185,12 @@ int ppo_step_bookkeeping(const float* reward, int64_t n, float* score_acc, float
 #define MLP_FRAG_T_FLOATS_ABI 53248
 int mlp_forward(const float* params, const float* params_frag, const float* x, int64_t n, float* mu_out, float* v_out,
                 float* out_save, float* h1_save, float* h2_save, float* h3_save, void* stream);
+/* ppo.py:214-220 in ONE launch: mu = Net.pi(x), act = mu + sqrt(var)*eps, log-prob of the unclipped
+ * act, act_out = clip(act, -1, 1).  eps, act_out f32 [n][18]; var f32 [18]; logp_out f32 [n];
+ * mu_out f32 [n][18] optional. */
+int mlp_forward_sample(const float* params, const float* params_frag, const float* x, int64_t n,
+                       const float* eps, const float* var, float* act_out, float* logp_out,
+                       float* mu_out, void* stream);
 
 
 /*

@@ -125,3 +125,46 @@ def test_graph_replay_matches_eager_rollout():
     for a, b in zip(res[False][:5], res[True][:5]):
         assert torch.equal(a, b)
     assert res[False][5] == res[True][5]
+
+
+@pytest.mark.parametrize("n", [33, 8192])
+def test_fused_forward_sample_matches_separate_kernels(n):
+    """mlp_forward_sample (policy + sampling in one launch) == mlp_forward then ppo_sample_logprob;
+    actions also bit-exact against the oracle's restatement of ppo.py:215-220."""
+    import ctypes as C
+    from fly_bproject_amd import _lib
+    from fly_bproject_amd.policy import PackedPolicy
+    from fly_bproject_amd.ppo import Net
+    from oracle import oracle as O
+    torch.manual_seed(n)
+    net = Net(73, 18).to("cuda:0")
+    pol = PackedPolicy(net, "cuda:0")
+    lib = _lib.load()
+    x = torch.randn(n, 73, device="cuda:0")
+    eps = torch.randn(n, 18, device="cuda:0")
+    var = torch.rand(18, device="cuda:0") * 0.19 + 0.01
+    p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    mu, _ = pol.forward(x, want_mu=True, want_v=False)
+    act1 = torch.empty(n, 18, device="cuda:0"); lp1 = torch.empty(n, device="cuda:0")
+    _lib.check(lib.ppo_sample_logprob(p(mu), p(var), p(eps), p(act1), p(lp1), n, None), "sample")
+    act2 = torch.empty(n, 18, device="cuda:0"); lp2 = torch.empty(n, device="cuda:0"); mu2 = torch.empty(n, 18, device="cuda:0")
+    _lib.check(lib.mlp_forward_sample(p(pol.P), p(pol.PF), p(x), n, p(eps), p(var), p(act2), p(lp2), p(mu2), None), "fused")
+    torch.cuda.synchronize()
+    assert torch.equal(mu, mu2) and torch.equal(act1, act2)
+    torch.testing.assert_close(lp1, lp2, rtol=2e-6, atol=1e-5)
+    a_o, lp_o = O.sample_logprob(mu.cpu().numpy(), var.cpu().numpy(), eps.cpu().numpy())
+    assert np.array_equal(act2.cpu().numpy(), a_o)
+    np.testing.assert_allclose(lp2.cpu().numpy(), lp_o, rtol=2e-6, atol=1e-5)
+
+
+def test_trainer_entry_point(tmp_path, capsys):
+    """trainer.py (reference trainer.py:1-50): bounded run, final save under the reference's key names."""
+    import trainer
+    policy = trainer.main(["--num_envs", "4096", "--headless", "True", "--max_steps", "165",
+                           "--save_path", str(tmp_path / "final_"), "--save_freq", "1000000"])
+    out = capsys.readouterr().out
+    assert "mini_chunk_size:  10" in out and "rollout_size:  160" in out and "Training" in out
+    assert "Steps: 0100 | Opt Step: 0000" in out                      # the reference's log line format
+    assert policy.optim_step == 75 and policy.run_step == 165
+    sd = torch.load(str(tmp_path / "final_.pth"), weights_only=True)  # policy.save() at exit (trainer.py:48)
+    assert "to_mean.2.weight" in sd and sd["shared_net.0.weight"].shape == (256, 73)
