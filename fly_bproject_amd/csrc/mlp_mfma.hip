@@ -911,7 +911,7 @@ extern "C" hipError_t flyhip_launch_mlp_backward_dx(const float* PT, const float
 }
 
 // workgroups per layer, proportional to the layer's share of the dW FLOPs (256 in total)
-static const int kGradWgs[4] = {68, 120, 52, 16};
+static const int kGradWgs[4] = {72, 112, 56, 16};   // multiples of 8: every layer spreads evenly over the 8 XCDs
 
 extern "C" int64_t flyhip_mlp_grad_workspace_floats(void)
 {
