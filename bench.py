@@ -260,6 +260,7 @@ def main():
         elapsed, rollout_s = float(tt[0]), float(tt[1])
     assert agent.optim_step == 75 * (a.warmup + a.steps), agent.optim_step
     finite = all(torch.isfinite(p).all().item() for p in agent.net.parameters())
+    ep_ret, ep_len, ep_cnt = agent.env.episode_stats()
     agent.exit()
 
     if rank == 0:
@@ -277,6 +278,8 @@ def main():
                        "parallelism": "dp%d" % world},
             "rollout_only_env_steps_per_s": round(world * a.num_envs * T / rollout_s, 1),
             "params_finite": finite,
+            "mean_episode_return": None if ep_cnt == 0 else round(ep_ret, 4),
+            "mean_episode_length": None if ep_cnt == 0 else round(ep_len, 2), "episodes_finished": ep_cnt,
         }
         ks = kernel_rooflines(a.num_envs, T, a.kernel_reps)
         line["roofline"] = ks[0]                     # the dominant kernel of one iteration

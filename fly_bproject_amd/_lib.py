@@ -15,7 +15,8 @@ class FlyHipError(RuntimeError):
 
 class FlyBuffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("root", "dof_state", "targets", "contact", "pot", "prev_pot",
-                                          "obs", "reward", "reset", "progress")]
+                                          "obs", "reward", "reset", "progress", "ep_return", "ep_length",
+                                          "done_return", "done_length", "done_count")]
 
 
 # name -> argtypes; every entry point returns int except fly_last_error

@@ -500,7 +500,18 @@ __global__ __launch_bounds__(BLOCK) void fly_kernel(const FlyConfig* __restrict_
         if (PH & (PH_RESET | PH_OBS)) { b.pot[e] = pot; b.prev_pot[e] = prev_pot; }
         if (PH & (PH_RESET | PH_REWARD)) b.reset[e] = (int64_t)rs;
         if (PH & (PH_RESET | PH_REWARD | PH_PROGRESS)) b.progress[e] = (int64_t)progress;
-        if (PH & PH_REWARD) b.reward[e] = reward;
+        if (PH & PH_REWARD) {
+            b.reward[e] = reward;
+            if (b.ep_return) {        // episode statistics (optional)
+                const float er = b.ep_return[e] + reward, el = b.ep_length[e] + 1.0f;
+                if (rs) {
+                    b.done_return[e] += er; b.done_length[e] += el; b.done_count[e] += 1.0f;
+                    b.ep_return[e] = 0.0f; b.ep_length[e] = 0.0f;
+                } else {
+                    b.ep_return[e] = er; b.ep_length[e] = el;
+                }
+            }
+        }
     }
 }
 

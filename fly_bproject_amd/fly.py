@@ -76,6 +76,13 @@ class Fly:
         base = torch.arange(n, device=dev, dtype=torch.long).view(n, 1) * NUM_CONTACT
         self.index_abdomen_sim = (base + torch.arange(0, 5, device=dev)).reshape(-1)     # fly.py:311-314
         self.index_legs_tip = (base + torch.arange(5, 11, device=dev)).reshape(-1)
+        # episode statistics kept by the step kernel (not in the reference): running return/length of
+        # the current episode and per-env totals over finished ones
+        self.episode_return_buf = torch.zeros(n, **f32)
+        self.episode_length_buf = torch.zeros(n, **f32)
+        self.finished_return_sum = torch.zeros(n, **f32)
+        self.finished_length_sum = torch.zeros(n, **f32)
+        self.finished_count = torch.zeros(n, **f32)
         self._bufs = _lib.FlyBuffers()
         self._refresh_pointers()
 
@@ -87,6 +94,9 @@ class Fly:
         b.pot, b.prev_pot = self.potentials.data_ptr(), self.prev_potentials.data_ptr()
         b.obs, b.reward = self.obs_buf.data_ptr(), self.reward_buf.data_ptr()
         b.reset, b.progress = self.reset_buf.data_ptr(), self.progress_buf.data_ptr()
+        b.ep_return, b.ep_length = self.episode_return_buf.data_ptr(), self.episode_length_buf.data_ptr()
+        b.done_return, b.done_length = self.finished_return_sum.data_ptr(), self.finished_length_sum.data_ptr()
+        b.done_count = self.finished_count.data_ptr()
 
     def bind_obs(self, rows):
         """Make `rows` (f32 [N,73], contiguous) the observation buffer: the
@@ -178,6 +188,39 @@ class Fly:
     def heading_vec(self):
         x = torch.tensor([1.0, 0.0, 0.0], device=self.device).expand(self.args.num_envs, 3)
         return self._quat_rotate(self.root_orientations, x)
+
+    def episode_stats(self, reset=False):
+        """(mean return, mean length, count) over the episodes finished since the last reset of the
+        statistics.  One host sync; call it when logging, not per step."""
+        cnt = float(self.finished_count.sum().item())
+        if cnt == 0:
+            out = (float("nan"), float("nan"), 0)
+        else:
+            out = (float(self.finished_return_sum.sum().item()) / cnt, float(self.finished_length_sum.sum().item()) / cnt, int(cnt))
+        if reset:
+            self.finished_return_sum.zero_(); self.finished_length_sum.zero_(); self.finished_count.zero_()
+        return out
+
+    def reward_terms(self):
+        """The per-term reward dump behind the reference viewer's P key (fly.py:504-546), as a dict
+        of [N] tensors computed from the current buffers (diagnostics; not on the hot path)."""
+        n, p = self.args.num_envs, self.params
+        obs = self.obs_buf
+        acts = self.actions.view(n, -1)
+        hw, uw = float(p.heading_weight), float(p.up_weight)
+        heading = torch.where(obs[:, 11] > 0.8, torch.full_like(obs[:, 11], hw), hw * obs[:, 11] / 0.8)
+        up = torch.where(obs[:, 0] > 1.4, torch.full_like(heading, uw), torch.zeros_like(heading))      # fly.py:512-513
+        q = self.root_orientations
+        orient = torch.where(q[:, 2] ** 2 + q[:, 3] ** 2 > 0.92, torch.full_like(up, uw), torch.zeros_like(up))   # fly.py:518
+        start = 12 + 2 * self.num_act
+        stored = obs[:, start:start + self.num_act]
+        elec = (acts - stored).abs().sum(-1)
+        lim = ((stored > self.dof_limits_upper * 0.9).sum(-1) + (stored < self.dof_limits_lower * 0.9).sum(-1))
+        legs = (self.force_tensor[self.index_legs_tip].sum(1).view(n, -1) > 0).long().sum(1) * 0.1
+        return {"heading_reward": heading, "alive_reward": torch.full_like(heading, 0.5), "up_reward": up,
+                "orient_reward": orient, "actions_cost": (acts ** 2).sum(-1), "electricity_cost": elec,
+                "dof_at_limit_cost": lim * float(p.joints_at_limit_cost_scale),
+                "progress_reward": self.potentials - self.prev_potentials, "leg_reward": legs}
 
     def render(self):
         """fly.py:487-562: there is no viewer in this build (headless only)."""

@@ -125,6 +125,15 @@ typedef struct FlyBuffers {
     float* reward;      /* [N] */
     int64_t* reset;     /* [N] */
     int64_t* progress;  /* [N] */
+    /* optional episode statistics (NULL = off), updated by fly_step / fly_pack_reward: the running
+     * return and length of the current episode, and per-env totals over finished episodes
+     * (sum of returns, sum of lengths, count).  Not in the reference; BASELINE's second metric
+     * (mean episode return) is read from here without a per-step host sync. */
+    float* ep_return;   /* [N] */
+    float* ep_length;   /* [N] */
+    float* done_return; /* [N] sum of returns of finished episodes */
+    float* done_length; /* [N] sum of lengths of finished episodes */
+    float* done_count;  /* [N] number of finished episodes */
 } FlyBuffers;
 
 const char* fly_last_error(void);

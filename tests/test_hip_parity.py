@@ -382,3 +382,35 @@ def test_abi_rejects_bad_arguments(lib):
     from fly_bproject_amd.fly import Fly
     with pytest.raises(lib.FlyHipError):
         Fly(make_args(16, sim_device="cpu"))                # no CPU path in the product
+
+
+def test_mean_episode_return_vs_oracle():
+    """BASELINE's second metric: mean episode return of the HIP sim vs the oracle on identical initial
+    states and action sequences, free-running (no re-sync).  Trajectories diverge chaotically at the
+    1e-6 level, so the comparison is statistical: same mean return / length within 5 %."""
+    n, steps = 1024, 300
+    cfg = O.default_config(n)
+    env = make_env(n)
+    s = O.EnvState(n)
+    rng = np.random.default_rng(4)
+    a0 = pose_actions(cfg, n)
+    drift = np.zeros((n, 18), np.float32)
+    ep_ret = np.zeros(n); ep_len = np.zeros(n); done_ret = []; done_len = []
+    for t in range(steps):
+        drift = 0.9 * drift + 0.25 * rng.normal(0, 1, (n, 18)).astype(np.float32)
+        a = np.clip(a0 + drift, -1, 1).astype(np.float32)
+        env.step(cuda(a))
+        O.env_step(cfg, s, a)
+        ep_ret += s.reward; ep_len += 1
+        fin = s.reset != 0
+        done_ret += list(ep_ret[fin]); done_len += list(ep_len[fin])
+        ep_ret[fin] = 0; ep_len[fin] = 0
+    mr, ml, cnt = env.episode_stats()
+    assert cnt > 200 and len(done_ret) > 200, "the action noise must finish enough episodes"
+    assert abs(cnt - len(done_ret)) <= 0.05 * len(done_ret) + 5
+    assert abs(mr - np.mean(done_ret)) <= 0.05 * abs(np.mean(done_ret)) + 0.05, (mr, np.mean(done_ret))
+    assert abs(ml - np.mean(done_len)) <= 0.05 * np.mean(done_len) + 1, (ml, np.mean(done_len))
+    terms = env.reward_terms()
+    assert set(terms) >= {"up_reward", "orient_reward", "electricity_cost", "dof_at_limit_cost", "leg_reward"}
+    assert float(terms["electricity_cost"].abs().max()) == 0.0           # Q4: identically zero upstream
+    env.exit()
