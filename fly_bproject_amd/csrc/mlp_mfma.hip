@@ -549,7 +549,7 @@ struct GradWLayer {
 struct GradWTable { GradWLayer l[4]; };
 
 constexpr int GW_ROWS = 32;      // rows staged per chunk (16 MFMA k-steps)
-constexpr int GW_THREADS = 512;  // 8 waves
+constexpr int GW_THREADS = 1024; // 16 waves: 4 per SIMD, so a wave's LDS/barrier stalls hide behind three others
 
 // One layer's slab.  Waves form a WN x WK grid over the (N/32) x (KPAD/32) output tiles; each wave
 // owns TNW x TKW tiles so one pair of operand reads feeds TNW*TKW MFMAs.  Chunks of 32 rows are
@@ -737,11 +737,11 @@ __global__ __launch_bounds__(GW_THREADS) void mlp_grad_w_kernel(GradWTable T, lo
     if (b >= T.l[3].first_block)
         grad_w_layer<MLP_OUT, MLP_H3, MLP_H3, MLP_H3, 1, 4, 1, 1>(T.l[3], nrows, b - T.l[3].first_block, lds_dyn);
     else if (b >= T.l[2].first_block)
-        grad_w_layer<MLP_H3, MLP_H2, MLP_H2, MLP_H2, 4, 2, 1, 2>(T.l[2], nrows, b - T.l[2].first_block, lds_dyn);
+        grad_w_layer<MLP_H3, MLP_H2, MLP_H2, MLP_H2, 4, 4, 1, 1>(T.l[2], nrows, b - T.l[2].first_block, lds_dyn);
     else if (b >= T.l[1].first_block)
-        grad_w_layer<MLP_H2, MLP_H1, MLP_H1, MLP_H1, 2, 4, 2, 2>(T.l[1], nrows, b - T.l[1].first_block, lds_dyn);
+        grad_w_layer<MLP_H2, MLP_H1, MLP_H1, MLP_H1, 4, 4, 1, 2>(T.l[1], nrows, b - T.l[1].first_block, lds_dyn);
     else
-        grad_w_layer<MLP_H1, MLP_IN, 96, MLP_IN_PAD, 8, 1, 1, 3>(T.l[0], nrows, b, lds_dyn);
+        grad_w_layer<MLP_H1, MLP_IN, 96, MLP_IN_PAD, 4, 3, 2, 1>(T.l[0], nrows, b, lds_dyn);
 }
 
 // sum the per-workgroup partials into the packed gradient buffer (layout of P).  A block handles 64
