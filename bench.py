@@ -103,7 +103,7 @@ def kernel_rooflines(num_envs, T, reps):
                                                        p(d["dz4"]), p(d["dz3"]), p(d["dz2"]), p(d["dz1"]),
                                                        p(pol.loss_part), _lib.stream_ptr()), reps)
     t_gw = _time_launches(lambda: lib.mlp_grad_w(p(x), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(d["dz1"]), p(d["dz2"]),
-                                                 p(d["dz3"]), p(d["dz4"]), rows, p(pol.workspace), p(pol.G),
+                                                 p(d["dz3"]), p(d["dz4"]), rows, p(pol.workspace), p(pol.G), None, None, None,
                                                  _lib.stream_ptr()), reps)
     t_adam = _time_launches(lambda: pol.adam_step(), reps)
 

@@ -29,11 +29,13 @@ extern "C" hipError_t flyhip_launch_mlp_backward_dx(const float* PT, const float
 extern "C" int64_t flyhip_mlp_grad_workspace_floats(void);
 extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, const float* h2, const float* h3,
                                                const float* dz1, const float* dz2, const float* dz3, const float* dz4,
-                                               int64_t n, float* workspace, float* grad_out, void* stream);
+                                               int64_t n, float* workspace, float* grad_out, const float* norm_mask,
+                                               float* norm_ws, int* norm_step, void* stream);
 extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PF, float* PT, const int* idx_f, const int* idx_t,
                                              const float* G, const float* mask, float* m,
                                              float* v, int* step, float lr, float beta1, float beta2, float eps,
-                                             float max_norm, float grad_scale, float* norm_ws, void* stream);
+                                             float max_norm, float grad_scale, float* norm_ws, int norm_ready,
+                                             void* stream);
 
 extern "C" hipError_t flyhip_launch_bookkeeping(const float* reward, int64_t n, float* score_acc, float score_scale,
                                                 float* action_var, int nvar, float var_decay, float var_min,
@@ -240,12 +242,16 @@ int mlp_backward_dx(const float* params_t, const float* out_saved, const float* 
 
 int mlp_grad_w(const float* x, const float* h1_saved, const float* h2_saved, const float* h3_saved,
                const float* dz1, const float* dz2, const float* dz3, const float* dz4, int64_t n,
-               float* workspace, float* grad, void* stream)
+               float* workspace, float* grad, const float* norm_mask, float* norm_ws, int32_t* norm_step,
+               void* stream)
 {
+    if ((norm_ws != nullptr) != (norm_mask != nullptr) || (norm_ws != nullptr) != (norm_step != nullptr))
+        return fail(FLY_E_ARG, "mlp_grad_w: norm_mask, norm_ws and norm_step go together");
     if (!x || !h1_saved || !h2_saved || !h3_saved || !dz1 || !dz2 || !dz3 || !dz4 || !workspace || !grad)
         return fail(FLY_E_ARG, "mlp_grad_w: null pointer");
     if (n <= 0) return fail(FLY_E_ARG, "mlp_grad_w: n must be > 0");
-    hipError_t e = flyhip_launch_mlp_grad_w(x, h1_saved, h2_saved, h3_saved, dz1, dz2, dz3, dz4, n, workspace, grad, stream);
+    hipError_t e = flyhip_launch_mlp_grad_w(x, h1_saved, h2_saved, h3_saved, dz1, dz2, dz3, dz4, n, workspace, grad, norm_mask,
+                                            norm_ws, norm_step, stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_grad_w launch");
     return FLY_OK;
 }
@@ -253,13 +259,13 @@ int mlp_grad_w(const float* x, const float* h1_saved, const float* h2_saved, con
 int mlp_adam_step(float* params, float* params_frag, float* params_t_frag, const int32_t* idx_frag,
                   const int32_t* idx_t_frag, const float* grad, const float* mask, float* exp_avg,
                   float* exp_avg_sq, int32_t* step, float lr, float beta1, float beta2, float eps,
-                  float max_norm, float grad_scale, float* norm_ws, void* stream)
+                  float max_norm, float grad_scale, float* norm_ws, int32_t norm_ready, void* stream)
 {
     if (!params || !params_frag || !params_t_frag || !idx_frag || !idx_t_frag || !grad || !mask || !exp_avg ||
         !exp_avg_sq || !step || !norm_ws)
         return fail(FLY_E_ARG, "mlp_adam_step: null pointer");
     hipError_t e = flyhip_launch_mlp_adam(params, params_frag, params_t_frag, idx_frag, idx_t_frag, grad, mask, exp_avg, exp_avg_sq, step, lr, beta1, beta2,
-                                          eps, max_norm, grad_scale, norm_ws, stream);
+                                          eps, max_norm, grad_scale, norm_ws, norm_ready, stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_adam_step launch");
     return FLY_OK;
 }

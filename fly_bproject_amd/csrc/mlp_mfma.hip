@@ -747,7 +747,12 @@ __global__ __launch_bounds__(GW_THREADS) void mlp_grad_w_kernel(GradWTable T, lo
 // sum the per-workgroup partials into the packed gradient buffer (layout of P).  A block handles 64
 // consecutive elements; its four waves each take every fourth partial slab (coalesced 256-byte
 // reads, eight loads in flight per lane) and the four partial sums meet in LDS.  Fixed order.
-__global__ __launch_bounds__(256) void mlp_grad_reduce_kernel(GradWTable T, float* __restrict__ G)
+// When `norm_ws` is given (single-rank runs: no all-reduce between here and the optimizer) the
+// block also leaves the sum of squares of its 64 masked gradient elements in norm_ws[1 + block] and
+// block 0 advances the step counter, which saves the separate norm launch of the optimizer step.
+__global__ __launch_bounds__(256) void mlp_grad_reduce_kernel(GradWTable T, float* __restrict__ G,
+                                                              const float* __restrict__ mask, float* __restrict__ norm_ws,
+                                                              int* __restrict__ step)
 {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -776,7 +781,22 @@ __global__ __launch_bounds__(256) void mlp_grad_reduce_kernel(GradWTable T, floa
     }
     red[wave][lane] = total;
     __syncthreads();
-    if (wave == 0 && i < MLP_PACKED_FLOATS) G[i] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (wave == 0) {
+        float g = 0.0f;
+        if (i < MLP_PACKED_FLOATS) {
+            g = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+            G[i] = g;
+        }
+        if (norm_ws) {
+            float ss = (i < MLP_PACKED_FLOATS) ? g * mask[i] : 0.0f;
+            ss *= ss;
+            for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
+            if (lane == 0) {
+                norm_ws[1 + blockIdx.x] = ss;
+                if (blockIdx.x == 0) *step += 1;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -818,13 +838,23 @@ __global__ __launch_bounds__(ADAM_THREADS) void mlp_adam_apply_kernel(float* __r
                                                                       float* __restrict__ m, float* __restrict__ v,
                                                                       const int* __restrict__ step, float lr, float beta1,
                                                                       float beta2, float eps, float max_norm,
-                                                                      float grad_scale, float* __restrict__ norm_ws)
+                                                                      float grad_scale, float* __restrict__ norm_ws,
+                                                                      int nparts, float part_scale)
 {
     __shared__ float s_coef;
+    __shared__ float red[16];
     const int tid = threadIdx.x;
+    {   // every block re-adds the same partial sums in the same order: identical clip coefficient
+        float t = 0.0f;
+        for (int b = tid; b < nparts; b += ADAM_THREADS) t += norm_ws[1 + b];
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+        if ((tid & 63) == 0) red[tid >> 6] = t;
+    }
+    __syncthreads();
     if (tid == 0) {
         float t = 0.0f;
-        for (int b = 0; b < ADAM_BLOCKS; ++b) t += norm_ws[1 + b];
+        for (int w = 0; w < 16; ++w) t += red[w];
+        t *= part_scale;                                    // partials of the unscaled gradient: scale^2
         const float norm = sqrtf(t);
         const float coef = max_norm / (norm + 1e-6f);          // torch.nn.utils.clip_grad_norm_
         s_coef = coef < 1.0f ? coef : 1.0f;
@@ -921,7 +951,8 @@ extern "C" int64_t flyhip_mlp_grad_workspace_floats(void)
 
 extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, const float* h2, const float* h3,
                                                const float* dz1, const float* dz2, const float* dz3, const float* dz4,
-                                               int64_t n, float* workspace, float* grad_out, void* stream)
+                                               int64_t n, float* workspace, float* grad_out, const float* norm_mask,
+                                               float* norm_ws, int* norm_step, void* stream)
 {
     GradWTable T;
     const float* dz[4] = {dz1, dz2, dz3, dz4};
@@ -952,20 +983,31 @@ extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((MLP_PACKED_FLOATS + 63) / 64), dim3(256), 0,
-                       (hipStream_t)stream, T, grad_out);
+                       (hipStream_t)stream, T, grad_out, norm_mask, norm_ws, norm_step);
     return hipGetLastError();
 }
+
+extern "C" int flyhip_mlp_reduce_blocks(void) { return (MLP_PACKED_FLOATS + 63) / 64; }
 
 extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PF, float* PT, const int* idx_f, const int* idx_t,
                                              const float* G, const float* mask, float* m,
                                              float* v, int* step, float lr, float beta1, float beta2, float eps,
-                                             float max_norm, float grad_scale, float* norm_ws, void* stream)
+                                             float max_norm, float grad_scale, float* norm_ws, int norm_ready,
+                                             void* stream)
 {
-    hipLaunchKernelGGL(mlp_adam_norm_kernel, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, G, mask,
-                       grad_scale, norm_ws, step);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    int nparts = ADAM_BLOCKS;
+    float part_scale = 1.0f;
+    if (norm_ready) {               // mlp_grad_w already left per-block sums of squares (unscaled) and advanced the step
+        nparts = (MLP_PACKED_FLOATS + 63) / 64;
+        part_scale = grad_scale * grad_scale;
+    } else {
+        hipLaunchKernelGGL(mlp_adam_norm_kernel, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, G, mask,
+                           grad_scale, norm_ws, step);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(mlp_adam_apply_kernel, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, P, PF, PT,
-                       idx_f, idx_t, G, mask, m, v, step, lr, beta1, beta2, eps, max_norm, grad_scale, norm_ws);
+                       idx_f, idx_t, G, mask, m, v, step, lr, beta1, beta2, eps, max_norm, grad_scale, norm_ws, nparts,
+                       part_scale);
     return hipGetLastError();
 }

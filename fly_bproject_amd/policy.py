@@ -141,7 +141,7 @@ class PackedPolicy:
         self.exp_avg = torch.zeros(PACKED, device=dev)
         self.exp_avg_sq = torch.zeros(PACKED, device=dev)
         self.step = torch.zeros(1, dtype=torch.int32, device=dev)
-        self._norm_ws = torch.zeros(128, device=dev)       # [0] = pre-clip gradient norm, rest scratch
+        self._norm_ws = torch.zeros(1280, device=dev)      # [0] = pre-clip gradient norm, rest partial sums
         self.grad_norm = self._norm_ws[:1]
         self.workspace = torch.empty(int(self._lib.mlp_grad_workspace_floats()), device=dev)
         self.max_rows = int(max_rows)
@@ -152,8 +152,10 @@ class PackedPolicy:
                    "dz2": torch.empty(r, H2, device=dev), "dz1": torch.empty(r, H1, device=dev)}
         self.loss_part = torch.zeros((r + 31) // 32, 2, device=dev)
 
-    def minibatch_grad(self, x, action, old_logp, adv, target, var, clip, global_rows=None):
-        """Forward + loss + backward of one minibatch; leaves the packed gradient in `self.G`."""
+    def minibatch_grad(self, x, action, old_logp, adv, target, var, clip, global_rows=None, fuse_norm=False):
+        """Forward + loss + backward of one minibatch; leaves the packed gradient in `self.G`.
+        `fuse_norm` (single rank): the partial reduction also prepares the clip norm and advances the
+        step, so `adam_step(norm_ready=True)` is one launch."""
         n = x.shape[0]
         assert n <= self.max_rows and x.is_contiguous() and action.is_contiguous()
         for t in (old_logp, adv, target):
@@ -168,8 +170,9 @@ class PackedPolicy:
                                              p(old_logp), p(adv), p(target), p(var), C.c_int64(n), C.c_float(inv_b),
                                              C.c_float(clip), p(d["dz4"]), p(d["dz3"]), p(d["dz2"]), p(d["dz1"]),
                                              p(self.loss_part), st), "mlp_backward_dx")
+        nm = (p(self.grad_mask), p(self._norm_ws), p(self.step)) if fuse_norm else (None, None, None)
         _lib.check(self._lib.mlp_grad_w(p(x), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(d["dz1"]), p(d["dz2"]),
-                                        p(d["dz3"]), p(d["dz4"]), C.c_int64(n), p(self.workspace), p(self.G), st),
+                                        p(d["dz3"]), p(d["dz4"]), C.c_int64(n), p(self.workspace), p(self.G), *nm, st),
                    "mlp_grad_w")
 
     def loss_value(self, n):
@@ -177,11 +180,11 @@ class PackedPolicy:
         parts = self.loss_part[: (n + 31) // 32].sum(0)
         return (parts[0] + parts[1]) / n
 
-    def adam_step(self, grad_scale=1.0):
+    def adam_step(self, grad_scale=1.0, norm_ready=False):
         p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
         _lib.check(self._lib.mlp_adam_step(p(self.P), p(self.PF), p(self.PT), p(self.idx_f), p(self.idx_t), p(self.G),
                                            p(self.grad_mask), p(self.exp_avg),
                                            p(self.exp_avg_sq), p(self.step), C.c_float(self.lr),
                                            C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
                                            C.c_float(self.max_norm), C.c_float(grad_scale), p(self._norm_ws),
-                                           _lib.stream_ptr()), "mlp_adam_step")
+                                           C.c_int(1 if norm_ready else 0), _lib.stream_ptr()), "mlp_adam_step")

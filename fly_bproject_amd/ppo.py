@@ -214,10 +214,11 @@ class PPO:
             for j in range(mc, self.rollout_size, mc):
                 pol.minibatch_grad(obs[k:j].view(rows, self.num_obs), action[k:j].view(rows, self.num_acts),
                                    old_log_prob[k:j].view(rows), advantage[k:j].view(rows),
-                                   target[k:j].view(rows), self.action_var, self.clip)
+                                   target[k:j].view(rows), self.action_var, self.clip,
+                                   fuse_norm=self.world_size == 1)
                 if self.world_size > 1:
                     dist.all_reduce(pol.G, op=dist.ReduceOp.SUM)    # 297 KB, latency-bound on xGMI
-                pol.adam_step(grad_scale=1.0 / self.world_size)
+                pol.adam_step(grad_scale=1.0 / self.world_size, norm_ready=self.world_size == 1)
                 self.optim_step += 1
                 k = j
 

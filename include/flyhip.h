@@ -211,13 +211,16 @@ int mlp_forward_sample(const float* params, const float* params_frag, const floa
  *                     loss_part [ceil(n/32)][2] (sum of -min(surr1,surr2), sum of huber).
  *   mlp_grad_w      : dW = dZ^T A and db = colsum(dZ) for all four layers into `grad`
  *                     (packed layout of `params`); `workspace` holds
- *                     mlp_grad_workspace_floats() floats.
+ *                     mlp_grad_workspace_floats() floats.  With norm_mask/norm_ws/norm_step
+ *                     non-NULL (single rank: nothing sits between this call and the optimizer)
+ *                     the reduction also leaves the clip-norm partial sums in norm_ws (>= 1280
+ *                     floats) and advances *norm_step; pass norm_ready = 1 to mlp_adam_step then.
  *   mlp_adam_step   : grad *= grad_scale; clip_grad_norm_(max_norm); Adam with torch defaults on
  *                     `params`; every updated weight is also scattered into params_frag /
  *                     params_t_frag through idx_frag / idx_t_frag (int32 [MLP_PACKED_FLOATS_ABI],
  *                     -1 = no copy).  `mask` (packed layout, 0/1)
  *                     freezes padding and structural zeros.  `step` is a device int counter;
- *                     `norm_ws` is a device scratch of >= 128 floats, norm_ws[0] returns the
+ *                     `norm_ws` is a device scratch of >= 1280 floats, norm_ws[0] returns the
  *                     pre-clip gradient norm.
  */
 int64_t mlp_grad_workspace_floats(void);
@@ -228,11 +231,12 @@ int mlp_backward_dx(const float* params_t_frag, const float* out_saved, const fl
                     float* dz1, float* loss_part, void* stream);
 int mlp_grad_w(const float* x, const float* h1_saved, const float* h2_saved, const float* h3_saved,
                const float* dz1, const float* dz2, const float* dz3, const float* dz4, int64_t n,
-               float* workspace, float* grad, void* stream);
+               float* workspace, float* grad, const float* norm_mask, float* norm_ws, int32_t* norm_step,
+               void* stream);
 int mlp_adam_step(float* params, float* params_frag, float* params_t_frag, const int32_t* idx_frag,
                   const int32_t* idx_t_frag, const float* grad, const float* mask, float* exp_avg,
                   float* exp_avg_sq, int32_t* step, float lr, float beta1, float beta2, float eps,
-                  float max_norm, float grad_scale, float* norm_ws, void* stream);
+                  float max_norm, float grad_scale, float* norm_ws, int32_t norm_ready, void* stream);
 
 
 /*

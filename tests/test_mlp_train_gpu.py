@@ -160,3 +160,19 @@ def test_ppo_hip_and_torch_updates_agree():
     moved = float((fn["torch"] - fn["init"]).norm())
     apart = float((fn["hip"] - fn["torch"]).norm())
     assert apart <= 0.2 * moved, (apart, moved)
+
+
+def test_fused_norm_step_matches_two_launch_step():
+    """Single-rank fast path (clip-norm partials produced by the gradient reduce, one optimizer
+    launch) vs the general path (separate norm launch): same norm, same parameters."""
+    outs = []
+    for fused in (False, True):
+        net, ref, pol, (x, action, old_logp, adv, target, var) = _setup(4099, 11)
+        for it in range(3):
+            pol.minibatch_grad(x, action, old_logp, adv * (30.0 if it == 1 else 1.0), target, var, 0.2, fuse_norm=fused)
+            pol.adam_step(norm_ready=fused)
+        outs.append((pol.P.clone(), float(pol.grad_norm), int(pol.step), pol.PF.clone()))
+    assert outs[0][2] == outs[1][2] == 3
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-5)
+    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(outs[0][3], outs[1][3], rtol=1e-5, atol=1e-7)

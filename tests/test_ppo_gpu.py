@@ -168,3 +168,19 @@ def test_trainer_entry_point(tmp_path, capsys):
     assert policy.optim_step == 75 and policy.run_step == 165
     sd = torch.load(str(tmp_path / "final_.pth"), weights_only=True)  # policy.save() at exit (trainer.py:48)
     assert "to_mean.2.weight" in sd and sd["shared_net.0.weight"].shape == (256, 73)
+
+
+def test_reference_default_env_count():
+    """trainer.py's default --num_envs 1000: rows per minibatch (40 000) and per step (1000) are not
+    multiples of the kernels' 16/32-row tiles; one full iteration stays finite and counts 75 steps."""
+    from fly_bproject_amd.ppo import PPO
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        agent = PPO(make_args(1000))
+    assert agent.mini_chunk_size == 40 and agent.rollout_size == 640
+    _run(agent, agent.rollout_size)
+    torch.cuda.synchronize()
+    assert agent.optim_step == 75
+    assert torch.isfinite(agent._obs_ring).all() and torch.isfinite(agent.policy.P).all()
+    assert torch.all(agent.policy.W1[:, 73:] == 0)
+    agent.exit()
