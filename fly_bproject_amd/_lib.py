@@ -33,6 +33,8 @@ SYMBOLS = {
     "fly_pack_reward": [_P, C.POINTER(FlyBuffers), _I, _P],
     "ppo_sample_logprob": [_P, _P, _P, _P, _P, _L, _P],
     "ppo_td_gae": [_P, _P, _P, _P, _F, _F, _L, _L, _P, _P, _I, _P],
+    "ppo_adv_stats": [_P, _L, _P, _P],
+    "ppo_adv_apply": [_P, _L, _P, _F, _F, _P],
     "ppo_step_bookkeeping": [_P, _L, _P, _F, _P, _I, _F, _F, _P],
     "mlp_forward": [_P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P],
     "mlp_forward_sample": [_P, _P, _P, _L, _P, _P, _P, _P, _P, _P],

@@ -51,6 +51,9 @@ extern "C" hipError_t flyhip_launch_mlp_forward_sample(const float* P, const flo
                                                        const float* eps, const float* var, float* act_out,
                                                        float* logp_out, float* mu_out, void* stream);
 
+extern "C" hipError_t flyhip_launch_adv_stats(const float* adv, int64_t n, float* stats, void* stream);
+extern "C" hipError_t flyhip_launch_adv_apply(float* adv, int64_t n, const float* totals, float count, float eps, void* stream);
+
 struct FlyEnv {
     FlyConfig host;
     FlyConfig* dev;
@@ -183,8 +186,26 @@ int ppo_td_gae(const float* reward, const float* v, const float* v_next, const f
 {
     if (!reward || !v || !v_next || !done || !target_out || !adv_out) return fail(FLY_E_ARG, "ppo_td_gae: null pointer");
     if (T <= 0 || N <= 0) return fail(FLY_E_ARG, "ppo_td_gae: T and N must be > 0");
+    if ((mode_flags & PPO_GAE_SCAN) && (mode_flags & PPO_GAE_MASK_RECURRENCE))
+        return fail(FLY_E_ARG, "ppo_td_gae: PPO_GAE_SCAN does not implement the masked recurrence");
     hipError_t e = flyhip_launch_td_gae(reward, v, v_next, done, gamma, lambda, T, N, target_out, adv_out, mode_flags, stream);
     if (e != hipSuccess) return hip_fail(e, "ppo_td_gae launch");
+    return FLY_OK;
+}
+
+int ppo_adv_stats(const float* adv, int64_t n, float* stats, void* stream)
+{
+    if (!adv || !stats || n <= 1) return fail(FLY_E_ARG, "ppo_adv_stats: bad argument");
+    hipError_t e = flyhip_launch_adv_stats(adv, n, stats, stream);
+    if (e != hipSuccess) return hip_fail(e, "ppo_adv_stats launch");
+    return FLY_OK;
+}
+
+int ppo_adv_apply(float* adv, int64_t n, const float* totals, float count, float eps, void* stream)
+{
+    if (!adv || !totals || n <= 0 || !(count > 1.0f)) return fail(FLY_E_ARG, "ppo_adv_apply: bad argument");
+    hipError_t e = flyhip_launch_adv_apply(adv, n, totals, count, eps, stream);
+    if (e != hipSuccess) return hip_fail(e, "ppo_adv_apply launch");
     return FLY_OK;
 }
 

@@ -85,6 +85,113 @@ __global__ __launch_bounds__(256) void ppo_td_gae_kernel(
 }
 
 
+// GAE as a wavefront scan, for the shapes where "lane = env" has nothing to run on: few envs, very
+// long rollouts (the reference's own 16-env configuration has T = 40 960, ppo.py:118-122).  One wave
+// per env; the 64 lanes own 64 consecutive chunks of the time axis.
+//   pass 1  every lane runs the recurrence over its chunk from a zero carry (its chunk's own
+//           contribution S_l) -- 64 chunks in parallel instead of one 40 960-long chain;
+//   carry   the carry into chunk l is A_l = S_{l+1} + c^{len(l+1)} A_{l+1}, a linear recurrence over
+//           lanes, solved with a 6-step Kogge-Stone scan of (multiplier, value) pairs on shuffles;
+//   pass 2  every lane reruns its chunk from the true carry and writes target / advantage.
+// Inside a chunk the arithmetic is the reference's (separately rounded mul/add); only the 63 carries
+// are re-associated, so the result agrees with the sequential loop to fp32 rounding (tested at
+// 1e-5), not bit for bit: the host picks this kernel only when N is small (PPO_GAE_SCAN).
+template <int MODE>
+__global__ __launch_bounds__(64) void ppo_td_gae_scan_kernel(
+    const float* __restrict__ reward, const float* __restrict__ v, const float* __restrict__ v_next,
+    const float* __restrict__ done, float gamma, float gl, long T, long N,
+    float* __restrict__ target_out, float* __restrict__ adv_out)
+{
+    const long e = blockIdx.x;
+    const int lane = threadIdx.x;
+    const long L = (T + 63) / 64;
+    // reverse time: lane 0 owns the LAST chunk, so the scan runs towards higher lanes
+    const long t_hi = T - (long)lane * L;                 // exclusive
+    const long t_lo = (t_hi - L > 0) ? t_hi - L : 0;
+    const float d_row = (MODE & PPO_GAE_DONE_PER_STEP) ? 0.0f : done[e];
+    auto delta_at = [&](long t, float& tg) {
+        const long i = t * N + e;
+        const float d = (MODE & PPO_GAE_DONE_PER_STEP) ? done[i] : d_row;
+        tg = __fadd_rn(reward[i], __fmul_rn(__fmul_rn(gamma, v_next[i]), d));
+        return __fsub_rn(tg, v[i]);
+    };
+    // pass 1: chunk contribution and multiplier
+    float S = 0.0f, m = 1.0f;
+    for (long t = t_hi - 1; t >= t_lo && t_hi > 0; --t) {
+        float tg;
+        const float dl = delta_at(t, tg);
+        S = __fadd_rn(__fmul_rn(gl, S), dl);
+        m *= gl;
+    }
+    if (t_hi <= 0) { S = 0.0f; m = 1.0f; }
+    // inclusive scan over lanes (lane 0 first in reverse time): value after chunk l given zero
+    // carry into chunk 0:  X_l = S_l + m_l * X_{l-1}
+    float sm = m, sv = S;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float pm = __shfl_up(sm, o, 64), pv = __shfl_up(sv, o, 64);
+        if (lane >= o) { sv = sv + sm * pv; sm = sm * pm; }
+    }
+    float carry = __shfl_up(sv, 1, 64);                   // advantage entering this chunk
+    if (lane == 0) carry = 0.0f;
+    // pass 2: the real recurrence from the true carry
+    float a = carry;
+    for (long t = t_hi - 1; t >= t_lo && t_hi > 0; --t) {
+        float tg;
+        const float dl = delta_at(t, tg);
+        const float cin = (MODE & PPO_GAE_MASK_RECURRENCE) ? 0.0f : a;   // masked recurrence is not supported here
+        a = __fadd_rn(__fmul_rn(gl, cin), dl);
+        target_out[t * N + e] = tg;
+        adv_out[t * N + e] = a;
+    }
+}
+
+// Advantage normalisation (named by BASELINE's north_star; the reference does NOT normalise,
+// ppo.py:171, so this is opt-in): per-block partial sums of x and x^2, then (x - mean) / (std + eps)
+// with the unbiased std torch uses.  Two launches; `stats` [2 + 2*blocks] is scratch, stats[0..1]
+// return mean and std.  With data-parallel ranks the caller all-reduces the two partial totals.
+__global__ __launch_bounds__(256) void ppo_adv_stats_kernel(const float* __restrict__ adv, long n,
+                                                            float* __restrict__ part)
+{
+    __shared__ float red[2][4];
+    float s = 0.0f, ss = 0.0f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float x = adv[i];
+        s += x; ss += x * x;
+    }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o, 64); ss += __shfl_down(ss, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        part[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void ppo_adv_apply_kernel(float* __restrict__ adv, long n, const float* __restrict__ totals,
+                                                            float count, float eps)
+{
+    const float mean = totals[0] / count;
+    const float var = fmaxf((totals[1] - count * mean * mean) / (count - 1.0f), 0.0f);
+    const float inv = 1.0f / (sqrtf(var) + eps);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        adv[i] = (adv[i] - mean) * inv;
+}
+
+__global__ __launch_bounds__(256) void ppo_adv_totals_kernel(const float* __restrict__ part, int blocks, float* __restrict__ totals)
+{
+    __shared__ float red[2][4];
+    float s = 0.0f, ss = 0.0f;
+    for (int b = threadIdx.x; b < blocks; b += 256) { s += part[2 * b]; ss += part[2 * b + 1]; }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_down(s, o, 64); ss += __shfl_down(ss, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        totals[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        totals[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
 // ppo.py:233 + :237 in one tiny launch: score += mean(reward)/num_eval_freq (kept on the device:
 // the reference's per-step .item() host sync is gone) and action_var = max(var_min, var - decay).
 // One workgroup, fixed reduction order: deterministic.
@@ -142,6 +249,15 @@ extern "C" hipError_t flyhip_launch_td_gae(const float* reward, const float* v, 
                                            float* target_out, float* adv_out, int mode, void* stream)
 {
     const float gl = (float)((double)gamma * (double)lambda);   // python double product, ppo.py:167
+    if (mode & PPO_GAE_SCAN) {
+        if (mode & PPO_GAE_DONE_PER_STEP)
+            hipLaunchKernelGGL((ppo_td_gae_scan_kernel<1>), dim3((unsigned)N), dim3(64), 0, (hipStream_t)stream, reward, v,
+                               v_next, done, gamma, gl, (long)T, (long)N, target_out, adv_out);
+        else
+            hipLaunchKernelGGL((ppo_td_gae_scan_kernel<0>), dim3((unsigned)N), dim3(64), 0, (hipStream_t)stream, reward, v,
+                               v_next, done, gamma, gl, (long)T, (long)N, target_out, adv_out);
+        return hipGetLastError();
+    }
     int block = 64;                                              // one wave per workgroup: spread envs over CUs
     int grid = (int)((N + block - 1) / block);
 #define GAE(M) hipLaunchKernelGGL((ppo_td_gae_kernel<M>), dim3(grid), dim3(block), 0, (hipStream_t)stream, \
@@ -153,5 +269,21 @@ extern "C" hipError_t flyhip_launch_td_gae(const float* reward, const float* v, 
     default: GAE(3); break;
     }
 #undef GAE
+    return hipGetLastError();
+}
+
+extern "C" hipError_t flyhip_launch_adv_stats(const float* adv, int64_t n, float* stats, void* stream)
+{
+    const int blocks = 256;
+    hipLaunchKernelGGL(ppo_adv_stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, adv, (long)n, stats + 2);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ppo_adv_totals_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats + 2, blocks, stats);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t flyhip_launch_adv_apply(float* adv, int64_t n, const float* totals, float count, float eps, void* stream)
+{
+    hipLaunchKernelGGL(ppo_adv_apply_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, adv, (long)n, totals, count, eps);
     return hipGetLastError();
 }

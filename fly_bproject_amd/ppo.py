@@ -98,6 +98,8 @@ class PPO:
         self._target = torch.zeros((T, n, 1), device=dev)
         self._eps_all = torch.zeros((T, n, self.num_acts), device=dev)   # one normal_() per rollout
         self._mu = torch.zeros((n, self.num_acts), device=dev)
+        self.normalize_advantage = bool(getattr(args, "normalize_advantage", False))
+        self._adv_stats = torch.zeros(514, device=dev)
         self.use_graph = bool(getattr(args, "graph", False))
         self._graphs = {}
         self._fwd_args = None
@@ -155,6 +157,8 @@ class PPO:
             done = self.all_done
             per_step = done.dim() == 3 and done.shape[0] == T and done.shape[1] == n
             mode = 1 if per_step else 0                             # reference path: [N,1]
+            if n < 512 and T >= 1024:
+                mode |= 4                                           # PPO_GAE_SCAN: few envs x long rollout
             done_f = done.to(torch.float32).contiguous()
             _lib.check(self._lib.ppo_td_gae(
                 C.c_void_p(self.all_reward.data_ptr()), C.c_void_p(values[:T].data_ptr()),
@@ -163,7 +167,23 @@ class PPO:
                 C.c_void_p(self._target.data_ptr()), C.c_void_p(self.all_advantage.data_ptr()),
                 C.c_int(mode), _lib.stream_ptr()), "ppo_td_gae")
             self._keep = (values, done_f)                           # alive until the stream has consumed them
+            if self.normalize_advantage:
+                self._normalize_advantage()
         return self.all_obs, self.all_acts, self.all_log_prob, self._target, self.all_advantage
+
+    def _normalize_advantage(self):
+        """Opt-in (`normalize_advantage`): adv <- (adv - mean) / (std + 1e-8) over the whole rollout of
+        ALL ranks.  Not in the reference (ppo.py:171 uses raw advantages); named by BASELINE's north_star."""
+        import torch.distributed as dist
+        cnt = self.all_advantage.numel()
+        p = lambda x: C.c_void_p(x.data_ptr())   # noqa: E731
+        _lib.check(self._lib.ppo_adv_stats(p(self.all_advantage), C.c_int64(cnt), p(self._adv_stats), _lib.stream_ptr()),
+                   "ppo_adv_stats")
+        if self.world_size > 1:
+            dist.all_reduce(self._adv_stats[:2], op=dist.ReduceOp.SUM)
+        _lib.check(self._lib.ppo_adv_apply(p(self.all_advantage), C.c_int64(cnt), p(self._adv_stats),
+                                           C.c_float(float(cnt * self.world_size)), C.c_float(1e-8), _lib.stream_ptr()),
+                   "ppo_adv_apply")
 
     def minibatch_loss(self, obs_mc, action_mc, old_log_prob_mc, target_mc, advantage_mc):
         """ppo.py:184-194.  Old log-prob is of the unclipped sample, the new one of the stored

@@ -63,6 +63,8 @@ extern "C" {
 #define PPO_GAE_COMPAT 0        /* reference semantics: done mask broadcast from a [N] row, no reset of the recurrence */
 #define PPO_GAE_DONE_PER_STEP 1 /* done is [T][N] instead of [N] */
 #define PPO_GAE_MASK_RECURRENCE 2 /* adv_t = delta_t + gamma*lambda*done_t*adv_{t+1} (non-reference) */
+#define PPO_GAE_SCAN 4          /* one wave per env, time on lanes, shuffle scan of the chunk carries: for
+                                   few envs x very long rollouts; agrees with the loop to fp32 rounding */
 
 /*
  * FlyConfig: everything fly.py hard-codes in Fly.__init__ / create_sim / create_envs
@@ -172,6 +174,14 @@ int ppo_sample_logprob(const float* mu, const float* var, const float* eps,
 int ppo_td_gae(const float* reward, const float* v, const float* v_next, const float* done,
                float gamma, float lambda, int64_t T, int64_t N,
                float* target_out, float* adv_out, int mode_flags, void* stream);
+
+/* Advantage normalisation (opt-in; the reference uses raw advantages, ppo.py:171).
+ *   ppo_adv_stats: stats[0] = sum(adv), stats[1] = sum(adv^2) over n elements (stats: >= 514 floats).
+ *   ppo_adv_apply: adv = (adv - mean) / (std + eps) with mean/std from totals[0..1] over `count`
+ *   elements (unbiased std, as torch.std).  Data-parallel callers all-reduce stats[0..1] and pass
+ *   the global count. */
+int ppo_adv_stats(const float* adv, int64_t n, float* stats, void* stream);
+int ppo_adv_apply(float* adv, int64_t n, const float* totals, float count, float eps, void* stream);
 
 /* ppo.py:233 and :237 without the per-step host sync: *score_acc += mean(reward) * score_scale;
  * action_var[j] = max(var_min, action_var[j] - var_decay) (skipped when var_decay <= 0). */

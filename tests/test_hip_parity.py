@@ -414,3 +414,37 @@ def test_mean_episode_return_vs_oracle():
     assert set(terms) >= {"up_reward", "orient_reward", "electricity_cost", "dof_at_limit_cost", "leg_reward"}
     assert float(terms["electricity_cost"].abs().max()) == 0.0           # Q4: identically zero upstream
     env.exit()
+
+
+@pytest.mark.parametrize("T,N,mode", [(40960, 16, 0), (640, 100, 1), (80, 8, 0), (3, 5, 0)])
+def test_td_gae_wave_scan_vs_sequential(lib, T, N, mode):
+    """PPO_GAE_SCAN (time on lanes, shuffle scan of chunk carries) against the oracle's sequential
+    loop: same TD targets bit for bit, advantages to fp32 rounding (carries are re-associated)."""
+    rng = np.random.default_rng(T + N)
+    r = rng.normal(0, 1, (T, N)).astype(np.float32); v = rng.normal(0, 1, (T, N)).astype(np.float32)
+    vn = rng.normal(0, 1, (T, N)).astype(np.float32)
+    d = (rng.random((T, N) if mode & 1 else (N,)) < 0.9).astype(np.float32)
+    tgt = torch.empty(T, N, device="cuda:0"); adv = torch.empty(T, N, device="cuda:0")
+    dr, dv, dvn, dd = cuda(r), cuda(v), cuda(vn), cuda(d)
+    lib.check(lib.load().ppo_td_gae(dr.data_ptr(), dv.data_ptr(), dvn.data_ptr(), dd.data_ptr(),
+                                    0.99, 0.95, T, N, tgt.data_ptr(), adv.data_ptr(), mode | 4, None), "gae scan")
+    torch.cuda.synchronize()
+    t2, a2 = O.td_gae(r, v, vn, d, mode_flags=mode)
+    assert np.array_equal(tgt.cpu().numpy(), t2)
+    np.testing.assert_allclose(adv.cpu().numpy(), a2, rtol=2e-5, atol=2e-5)
+    assert lib.load().ppo_td_gae(dr.data_ptr(), dv.data_ptr(), dvn.data_ptr(), dd.data_ptr(), 0.99, 0.95, T, N,
+                                 tgt.data_ptr(), adv.data_ptr(), 4 | 2, None) == -1      # masked recurrence: rejected
+
+
+@pytest.mark.parametrize("n", [655360, 1000, 7])
+def test_advantage_normalisation(lib, n):
+    rng = np.random.default_rng(n)
+    a = (rng.normal(0.3, 2.0, n)).astype(np.float32)
+    da = cuda(a); stats = torch.zeros(514, device="cuda:0")
+    l = lib.load()
+    lib.check(l.ppo_adv_stats(da.data_ptr(), n, stats.data_ptr(), None), "stats")
+    lib.check(l.ppo_adv_apply(da.data_ptr(), n, stats.data_ptr(), float(n), 1e-8, None), "apply")
+    torch.cuda.synchronize()
+    want = (a.astype(np.float64) - a.astype(np.float64).mean()) / (a.astype(np.float64).std(ddof=1) + 1e-8)
+    np.testing.assert_allclose(da.cpu().numpy(), want, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(float(stats[0]), a.astype(np.float64).sum(), rtol=1e-4, atol=1e-2)
