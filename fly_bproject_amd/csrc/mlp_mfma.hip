@@ -239,6 +239,15 @@ __global__ __launch_bounds__(THREADS, 3) void mlp_forward_kernel(
         }
     };
 
+    // De-phase the workgroups that share a CU.  They run the same program on the same clock, so
+    // without a nudge all three sit in their MFMA loops together (3x contention) and then in their
+    // epilogues together (matrix pipe idle).  Workgroups b, b+256, b+512 are the ones the dispatcher
+    // co-locates first; delaying the second and third by one and two thirds of a tile's solo time
+    // lets one group's epilogue hide under the others' MFMAs.  Speed only, never correctness.
+    {
+        const int slot = (blockIdx.x >> 8) % 3;
+        for (int i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(127);     // 127 * 64 cycles each
+    }
     long tile = blockIdx.x;
     if (tile < ntiles) x_load(tile);
     for (; tile < ntiles; tile += gridDim.x) {
@@ -433,6 +442,10 @@ __global__ __launch_bounds__(THREADS, 3) void mlp_backward_dx_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long row0 = (long)blockIdx.x * BM;
 
+    {   // de-phase co-resident workgroups (see mlp_forward_kernel)
+        const int slot = (blockIdx.x >> 8) % 3;
+        for (int i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     TileRegs<MLP_H3> h3r;
     tile_load<MLP_H3>(h3r, h3_saved, row0, n, tid);       // in flight during the loss phase
 

@@ -10,12 +10,15 @@ What changed underneath (MI355X-first, not a translation):
     are views (next_obs[t] is obs[t+1] by construction, ppo.py:210/:228), and the env kernel
     writes each observation row straight into the ring (`Fly.bind_obs`), so the two 2.4 MB
     row copies per step are gone;
-  * sampling + log-prob + clip is one kernel writing into the rollout rows (`ppo_sample_logprob`);
+  * the policy forward, sampling, log-prob and clip are ONE launch writing the action / log-prob rows
+    of the rollout in place (`mlp_forward_sample`);
   * TD target + GAE is one kernel (`ppo_td_gae`) instead of a T-long Python loop, and the two
     critic passes over the rollout collapse into one pass over the ring;
   * no per-step host sync: the score accumulates on the device and is read every
     `num_eval_freq` steps, when it is printed;
-  * data-parallel training: one flat-gradient all-reduce over RCCL per optimizer step.
+  * the update runs on the MFMA kernels of csrc/mlp_mfma.hip (forward, loss + dX chain, dW, clip +
+    Adam) over contiguous minibatch slices of the rollout;
+  * data-parallel training: one packed-gradient all-reduce over RCCL per optimizer step.
 """
 import ctypes as C
 
@@ -245,7 +248,7 @@ class PPO:
     # ------------------------------------------------------------------------------------------
     def _prepare_step_args(self):
         """Every pointer of step t is a fixed row of a preallocated rollout tensor, so the ctypes
-        argument tuples of the four launches are built ONCE per t: a step then costs four foreign
+        argument tuples of the three launches are built ONCE per t: a step then costs three foreign
         calls and two attribute stores on the host (the rollout was host-bound at ~50 us/step
         against ~35 us of GPU work)."""
         T, n = self.rollout_size, int(self.args.num_envs)
@@ -254,16 +257,15 @@ class PPO:
         self._obs_rows = [self._obs_ring[t] for t in range(T + 1)]
         self._reward_rows = [self.all_reward[t].view(-1) for t in range(T)]
         self._act_rows = [self.all_acts[t] for t in range(T)]
-        fwd, smp, book, bufs = [], [], [], []
+        fwd, book, bufs = [], [], []
         for t in range(T):
             fwd.append((P(pol.P.data_ptr()), P(pol.PF.data_ptr()), P(self._obs_rows[t].data_ptr()), C.c_int64(n),
                         P(self._eps_all[t].data_ptr()), P(self.action_var.data_ptr()), P(self._act_rows[t].data_ptr()),
                         P(self.all_log_prob[t].data_ptr()), None))
-            smp.append(None)
             book.append((P(self._reward_rows[t].data_ptr()), C.c_int64(n), P(self._score_acc.data_ptr()),
                          C.c_float(1.0 / self.num_eval_freq), P(self.action_var.data_ptr()), C.c_int(self.num_acts)))
             bufs.append((self._obs_rows[t + 1].data_ptr(), self._reward_rows[t].data_ptr()))
-        self._fwd_args, self._smp_args, self._book_args, self._buf_ptrs = fwd, smp, book, bufs
+        self._fwd_args, self._book_args, self._buf_ptrs = fwd, book, bufs
         self._var_min = C.c_float(0.01)
 
     def _launch_step(self, t):

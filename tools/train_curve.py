@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Does the loop learn?  Runs ITERS PPO iterations at N envs and prints, per iteration, the mean
 per-step reward of the rollout and the episode statistics (mean return / length of finished
-episodes).  Usage: python tools/train_curve.py [ITERS] [N] [backend]"""
+episodes).  Usage: python tools/train_curve.py [ITERS] [N] [backend] [variant]"""
 import contextlib
 import io
 import os
@@ -17,9 +17,10 @@ from fly_bproject_amd.ppo import PPO  # noqa: E402
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 backend = sys.argv[3] if len(sys.argv) > 3 else "hip"
+variant = sys.argv[4] if len(sys.argv) > 4 else "bigGrav"
 torch.manual_seed(0)
 with contextlib.redirect_stdout(io.StringIO()):
-    agent = PPO(make_args(n, update_backend=backend))
+    agent = PPO(make_args(n, update_backend=backend, variant=variant))
 t0 = time.perf_counter()
 for it in range(iters):
     with contextlib.redirect_stdout(io.StringIO()):
