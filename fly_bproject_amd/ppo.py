@@ -132,6 +132,11 @@ class PPO:
         self._gen = torch.Generator(device=dev)
         self._gen.manual_seed(int(getattr(args, "seed", 0)) + 1000003 * int(getattr(args, "rank", 0)))
         self.world_size = int(getattr(args, "world_size", 1))
+        # "grad_allreduce" (default): one packed-gradient all-reduce per optimizer step = the reference's
+        # update on the global minibatch.  "param_average": one exchange per PPO update (non-parity).
+        self.dp_mode = getattr(args, "dp_mode", "grad_allreduce")
+        if self.dp_mode not in ("grad_allreduce", "param_average"):
+            raise ValueError("dp_mode must be grad_allreduce or param_average")
         self._flat_grad = None
         if self.world_size > 1:
             from .dist import FlatGradAllReduce
@@ -232,18 +237,27 @@ class PPO:
         mc, n = self.mini_chunk_size, int(self.args.num_envs)
         rows = mc * n
         pol = self.policy
+        sync_grads = self.world_size > 1 and self.dp_mode == "grad_allreduce"
         for _ in range(self.epoch):
             k = 0
             for j in range(mc, self.rollout_size, mc):
                 pol.minibatch_grad(obs[k:j].view(rows, self.num_obs), action[k:j].view(rows, self.num_acts),
                                    old_log_prob[k:j].view(rows), advantage[k:j].view(rows),
                                    target[k:j].view(rows), self.action_var, self.clip,
-                                   fuse_norm=self.world_size == 1)
-                if self.world_size > 1:
+                                   fuse_norm=not sync_grads)
+                if sync_grads:
                     dist.all_reduce(pol.G, op=dist.ReduceOp.SUM)    # 297 KB, latency-bound on xGMI
-                pol.adam_step(grad_scale=1.0 / self.world_size, norm_ready=self.world_size == 1)
+                pol.adam_step(grad_scale=1.0 / self.world_size if sync_grads else 1.0, norm_ready=not sync_grads)
                 self.optim_step += 1
                 k = j
+        if self.world_size > 1 and not sync_grads:
+            # dp_mode "param_average": ONE exchange per PPO update (BASELINE's north_star wording) --
+            # ranks take their 75 optimizer steps locally, then parameters and Adam moments are
+            # averaged.  NOT the reference algorithm on a larger batch (that is the default mode).
+            for buf in (pol.P, pol.exp_avg, pol.exp_avg_sq):
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+                buf.div_(self.world_size)
+            pol.refresh()
 
     # ------------------------------------------------------------------------------------------
     def _prepare_step_args(self):

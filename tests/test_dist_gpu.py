@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, dp_mode="grad_allreduce"):
     sys.path.insert(0, REPO)
     import contextlib
     import io
@@ -32,7 +32,7 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     torch.manual_seed(10 + rank)                      # different init per rank: the broadcast must fix it
     with contextlib.redirect_stdout(io.StringIO()):
-        agent = PPO(make_args(2048, rank=rank, world_size=world, seed=0))
+        agent = PPO(make_args(2048, rank=rank, world_size=world, seed=0, dp_mode=dp_mode))
         broadcast_policy(agent)
         for _ in range(agent.rollout_size):
             agent.run()
@@ -45,9 +45,10 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_one_gpu(tmp_path):
+@pytest.mark.parametrize("dp_mode", ["grad_allreduce", "param_average"])
+def test_two_ranks_one_gpu(tmp_path, dp_mode):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), dp_mode), nprocs=2, join=True)
     a = torch.load(tmp_path / "r0.pt", weights_only=True)
     b = torch.load(tmp_path / "r1.pt", weights_only=True)
     assert a["finite"] and b["finite"]

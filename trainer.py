@@ -36,6 +36,9 @@ def parse_args(argv=None):
     parser.add_argument('--reward', type=str, default="standing", choices=["standing", "walking"])
     parser.add_argument('--max_steps', type=int, default=0, help='stop after this many env steps (0 = run until env.end)')
     parser.add_argument('--seed', type=int, default=0)
+    parser.add_argument('--dp_mode', type=str, default="grad_allreduce", choices=["grad_allreduce", "param_average"],
+                        help='multi-GPU: all-reduce the gradient every optimizer step (reference algorithm on the global '
+                             'batch) or average parameters once per PPO update (non-parity)')
     parser.add_argument('--normalize_advantage', action='store_true',
                         help='normalise advantages over the rollout (not in the reference; off by default)')
     args = parser.parse_args(argv)
