@@ -143,7 +143,7 @@ def kernel_rooflines(num_envs, T, reps):
     grids = {"fly_kernel<63> (fly_step)": ("fly_kernel<63>", ((num_envs + 15) // 16) * 256),
              "mlp_forward_kernel": ("mlp_forward_kernel", ((rows + 31) // 32) * 256),
              "mlp_backward_dx_kernel": ("mlp_backward_dx_kernel", ((rows + 31) // 32) * 256),
-             "mlp_grad_w_kernel (+reduce)": ("mlp_grad_w_kernel", 256 * 512)}
+             "mlp_grad_w_kernel (+reduce)": ("mlp_grad_w_kernel", 256 * 1024)}
     for k in ks:
         key = grids.get(k["kernel"])
         if key:
