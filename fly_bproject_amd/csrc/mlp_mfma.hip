@@ -556,7 +556,7 @@ __global__ __launch_bounds__(THREADS, 3) void mlp_backward_dx_kernel(
 struct GradWLayer {
     const float* dz;      // [rows][N]
     const float* a;       // [rows][Ka]  (row pitch Ka; K <= KP columns used, padded with zeros to KP)
-    float* partial;       // [wgs][N][KP + 1]  (last column: bias gradient)
+    float* partial;       // [wgs][N*KP + N]: the layer's packed gradient block (weights, then biases) per workgroup
     int N, Ka, KP, wgs, first_block;
 };
 struct GradWTable { GradWLayer l[4]; };
@@ -713,7 +713,7 @@ __device__ void grad_w_layer(const GradWLayer& L, long nrows, int wg, float* lds
         __syncthreads();
         cur ^= 1;
     }
-    float* out = L.partial + (long)wg * N * (KOUT + 1);
+    float* out = L.partial + (long)wg * (N * KOUT + N);
     if (active) {
 #pragma unroll
         for (int a = 0; a < TNW; ++a)
@@ -724,7 +724,7 @@ __device__ void grad_w_layer(const GradWLayer& L, long nrows, int wg, float* lds
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int row = wn * (TNW * 32) + 32 * a + acc_row(reg, lane);   // n index
-                        out[row * (KOUT + 1) + col] = acc[a][b][reg];
+                        out[row * KOUT + col] = acc[a][b][reg];
                     }
                 }
             }
@@ -738,7 +738,7 @@ __device__ void grad_w_layer(const GradWLayer& L, long nrows, int wg, float* lds
             float s = 0.0f;
 #pragma unroll
             for (int p = 0; p < PARTS; ++p) s += lds[p * N + tid];
-            out[tid * (KOUT + 1) + KOUT] = s;
+            out[N * KOUT + tid] = s;
         }
     }
 }
@@ -757,53 +757,71 @@ __global__ __launch_bounds__(GW_THREADS) void mlp_grad_w_kernel(GradWTable T, lo
         grad_w_layer<MLP_H1, MLP_IN, 96, MLP_IN_PAD, 4, 3, 2, 1>(T.l[0], nrows, b, lds_dyn);
 }
 
-// sum the per-workgroup partials into the packed gradient buffer (layout of P).  A block handles 64
-// consecutive elements; its four waves each take every fourth partial slab (coalesced 256-byte
-// reads, eight loads in flight per lane) and the four partial sums meet in LDS.  Fixed order.
+// sum the per-workgroup partials into the packed gradient buffer.  Every partial slab has the
+// layout of its layer's block of P (weights then biases), so this is an elementwise sum over
+// slabs: a block owns 64 consecutive float4 (one per lane), its sixteen waves each take every sixteenth
+// slab with all their 16-byte loads in flight, and the sixteen sums meet in LDS.  Fixed order.
 // When `norm_ws` is given (single-rank runs: no all-reduce between here and the optimizer) the
-// block also leaves the sum of squares of its 64 masked gradient elements in norm_ws[1 + block] and
+// block also leaves the sum of squares of its masked gradient elements in norm_ws[1 + block] and
 // block 0 advances the step counter, which saves the separate norm launch of the optimizer step.
-__global__ __launch_bounds__(256) void mlp_grad_reduce_kernel(GradWTable T, float* __restrict__ G,
-                                                              const float* __restrict__ mask, float* __restrict__ norm_ws,
-                                                              int* __restrict__ step)
+constexpr int RED_WAVES = 16;
+constexpr int RED_BLOCKS = (MLP_PACKED_FLOATS / 4 + 63) / 64;          // 291
+
+__global__ __launch_bounds__(64 * RED_WAVES) void mlp_grad_reduce_kernel(GradWTable T, float* __restrict__ G,
+                                                                         const float* __restrict__ mask,
+                                                                         float* __restrict__ norm_ws, int* __restrict__ step)
 {
-    __shared__ float red[4][64];
+    __shared__ float4 red[RED_WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + lane;
-    float total = 0.0f;
-    if (i < MLP_PACKED_FLOATS) {
-        int layer, off_w, off_b, N, KP;
-        if (i < MLP_OFF_W2) { layer = 0; off_w = MLP_OFF_W1; off_b = MLP_OFF_B1; N = MLP_H1; KP = MLP_IN_PAD; }
-        else if (i < MLP_OFF_W3) { layer = 1; off_w = MLP_OFF_W2; off_b = MLP_OFF_B2; N = MLP_H2; KP = MLP_H1; }
-        else if (i < MLP_OFF_W4) { layer = 2; off_w = MLP_OFF_W3; off_b = MLP_OFF_B3; N = MLP_H3; KP = MLP_H2; }
-        else { layer = 3; off_w = MLP_OFF_W4; off_b = MLP_OFF_B4; N = MLP_OUT; KP = MLP_H3; }
+    const int q = blockIdx.x * 64 + lane;                      // float4 index into the packed buffer
+    const int o = 4 * q;
+    float4 total = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (o < MLP_PACKED_FLOATS) {
+        int layer, off_w, N, KP;
+        if (o < MLP_OFF_W2) { layer = 0; off_w = MLP_OFF_W1; N = MLP_H1; KP = MLP_IN_PAD; }
+        else if (o < MLP_OFF_W3) { layer = 1; off_w = MLP_OFF_W2; N = MLP_H2; KP = MLP_H1; }
+        else if (o < MLP_OFF_W4) { layer = 2; off_w = MLP_OFF_W3; N = MLP_H3; KP = MLP_H2; }
+        else { layer = 3; off_w = MLP_OFF_W4; N = MLP_OUT; KP = MLP_H3; }
         const float* part = layer == 0 ? T.l[0].partial : layer == 1 ? T.l[1].partial : layer == 2 ? T.l[2].partial : T.l[3].partial;
         const int wgs = layer == 0 ? T.l[0].wgs : layer == 1 ? T.l[1].wgs : layer == 2 ? T.l[2].wgs : T.l[3].wgs;
-        long idx;
-        if (i < off_b) { const int rr = (i - off_w) / KP, cc = (i - off_w) - rr * KP; idx = (long)rr * (KP + 1) + cc; }
-        else idx = (long)(i - off_b) * (KP + 1) + KP;
-        const long stride = (long)N * (KP + 1);
-        float s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int w = wave;
-        for (; w + 28 < wgs; w += 32) {
+        const long stride = (long)N * KP + N;
+        const float4* p4 = reinterpret_cast<const float4*>(part + (o - off_w));
+        const long s4 = stride / 4;
+        float4 acc4[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s8[u] += part[(w + 4 * u) * stride + idx];
+        for (int u = 0; u < 4; ++u) acc4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int w0 = wave; w0 < wgs; w0 += 4 * RED_WAVES) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int w = w0 + u * RED_WAVES;
+                v[u] = w < wgs ? p4[(long)w * s4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc4[u].x += v[u].x; acc4[u].y += v[u].y; acc4[u].z += v[u].z; acc4[u].w += v[u].w; }
         }
-        for (int u = 0; w < wgs; w += 4, ++u) s8[u & 7] += part[w * stride + idx];
-        total = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+        total.x = (acc4[0].x + acc4[1].x) + (acc4[2].x + acc4[3].x);
+        total.y = (acc4[0].y + acc4[1].y) + (acc4[2].y + acc4[3].y);
+        total.z = (acc4[0].z + acc4[1].z) + (acc4[2].z + acc4[3].z);
+        total.w = (acc4[0].w + acc4[1].w) + (acc4[2].w + acc4[3].w);
     }
     red[wave][lane] = total;
     __syncthreads();
     if (wave == 0) {
-        float g = 0.0f;
-        if (i < MLP_PACKED_FLOATS) {
-            g = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-            G[i] = g;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (o < MLP_PACKED_FLOATS) {
+#pragma unroll
+            for (int w = 0; w < RED_WAVES; ++w) { g.x += red[w][lane].x; g.y += red[w][lane].y; g.z += red[w][lane].z; g.w += red[w][lane].w; }
+            *reinterpret_cast<float4*>(G + o) = g;
         }
         if (norm_ws) {
-            float ss = (i < MLP_PACKED_FLOATS) ? g * mask[i] : 0.0f;
-            ss *= ss;
-            for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
+            float ss = 0.0f;
+            if (o < MLP_PACKED_FLOATS) {
+                const float4 mk = *reinterpret_cast<const float4*>(mask + o);
+                const float a = g.x * mk.x, b = g.y * mk.y, c = g.z * mk.z, d = g.w * mk.w;
+                ss = (a * a + b * b) + (c * c + d * d);
+            }
+            for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
             if (lane == 0) {
                 norm_ws[1 + blockIdx.x] = ss;
                 if (blockIdx.x == 0) *step += 1;
@@ -959,7 +977,7 @@ static const int kGradWgs[4] = {72, 112, 56, 16};   // multiples of 8: every lay
 extern "C" int64_t flyhip_mlp_grad_workspace_floats(void)
 {
     return (int64_t)kGradWgs[0] * MLP_H1 * (MLP_IN_PAD + 1) + (int64_t)kGradWgs[1] * MLP_H2 * (MLP_H1 + 1) +
-           (int64_t)kGradWgs[2] * MLP_H3 * (MLP_H2 + 1) + (int64_t)kGradWgs[3] * MLP_OUT * (MLP_H3 + 1);
+           (int64_t)kGradWgs[2] * MLP_H3 * (MLP_H2 + 1) + (int64_t)kGradWgs[3] * MLP_OUT * (MLP_H3 + 1);   // N*KP + N per slab
 }
 
 extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, const float* h2, const float* h3,
@@ -978,7 +996,7 @@ extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, 
     for (int l = 0; l < 4; ++l) {
         T.l[l].dz = dz[l]; T.l[l].a = a[l]; T.l[l].partial = ws;
         T.l[l].N = N[l]; T.l[l].Ka = Ka[l]; T.l[l].KP = KP[l]; T.l[l].wgs = kGradWgs[l]; T.l[l].first_block = first;
-        ws += (long)kGradWgs[l] * N[l] * (KP[l] + 1);
+        ws += (long)kGradWgs[l] * ((long)N[l] * KP[l] + N[l]);
         first += kGradWgs[l];
     }
     // dynamic LDS: the largest layer's staging tiles: max over layers of 32*(N + TK*32) floats
@@ -995,12 +1013,12 @@ extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, 
     hipLaunchKernelGGL(mlp_grad_w_kernel, dim3(first), dim3(GW_THREADS), lds_bytes, (hipStream_t)stream, T, (long)n);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((MLP_PACKED_FLOATS + 63) / 64), dim3(256), 0,
+    hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3(RED_BLOCKS), dim3(64 * RED_WAVES), 0,
                        (hipStream_t)stream, T, grad_out, norm_mask, norm_ws, norm_step);
     return hipGetLastError();
 }
 
-extern "C" int flyhip_mlp_reduce_blocks(void) { return (MLP_PACKED_FLOATS + 63) / 64; }
+extern "C" int flyhip_mlp_reduce_blocks(void) { return RED_BLOCKS; }
 
 extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PF, float* PT, const int* idx_f, const int* idx_t,
                                              const float* G, const float* mask, float* m,
@@ -1011,7 +1029,7 @@ extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PF, float* PT, con
     int nparts = ADAM_BLOCKS;
     float part_scale = 1.0f;
     if (norm_ready) {               // mlp_grad_w already left per-block sums of squares (unscaled) and advanced the step
-        nparts = (MLP_PACKED_FLOATS + 63) / 64;
+        nparts = RED_BLOCKS;
         part_scale = grad_scale * grad_scale;
     } else {
         hipLaunchKernelGGL(mlp_adam_norm_kernel, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, G, mask,
