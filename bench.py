@@ -121,8 +121,8 @@ def kernel_rooflines(num_envs, T, reps):
                 "avg_launch_us": round(dur * 1e6, 3), "algorithmic_per_launch": flop_per_launch,
                 "launches_per_iteration": per_iter, "iteration_share_ms": round(dur * per_iter * 1e3, 3)}
 
-    critic_rows = (T + 1) * num_envs
-    fwd_equiv_launches = 75 + critic_rows / rows + T * num_envs / rows      # update + critic pass + rollout policy
+    critic_rows = num_envs        # v(obs_t) falls out of the rollout launches; make_data evaluates the last next_obs only
+    fwd_equiv_launches = 75 + critic_rows / rows + T * num_envs / rows      # update + critic rows + rollout policy
     ks = [
         hbm("fly_kernel<63> (fly_step)", t_step, FUSED_STEP_BYTES_PER_ENV * num_envs, T),
         mfma("mlp_forward_kernel", t_fwd, MLP_FWD_FLOP * rows, round(fwd_equiv_launches, 2)),

@@ -49,7 +49,7 @@ extern "C" hipError_t flyhip_launch_dqn_huber_td(const float* q_table, const flo
 
 extern "C" hipError_t flyhip_launch_mlp_forward_sample(const float* P, const float* PF, const float* x, int64_t n,
                                                        const float* eps, const float* var, float* act_out,
-                                                       float* logp_out, float* mu_out, void* stream);
+                                                       float* logp_out, float* mu_out, float* v_out, void* stream);
 
 extern "C" hipError_t flyhip_launch_adv_stats(const float* adv, int64_t n, float* stats, void* stream);
 extern "C" hipError_t flyhip_launch_adv_apply(float* adv, int64_t n, const float* totals, float count, float eps, void* stream);
@@ -115,7 +115,7 @@ int launch(FlyHandle h, int phases, const float* actions, const FlyBuffers* b, v
 extern "C" {
 
 const char* fly_last_error(void) { return g_err; }
-int fly_abi_version(void) { return 1; }
+int fly_abi_version(void) { return 2; }
 
 int fly_create(const FlyConfig* cfg, FlyHandle* out)
 {
@@ -232,12 +232,12 @@ int mlp_forward(const float* params, const float* params_frag, const float* x, i
 
 int mlp_forward_sample(const float* params, const float* params_frag, const float* x, int64_t n,
                        const float* eps, const float* var, float* act_out, float* logp_out,
-                       float* mu_out, void* stream)
+                       float* mu_out, float* v_out, void* stream)
 {
     if (!params || !params_frag || !x || !eps || !var || !act_out || !logp_out)
         return fail(FLY_E_ARG, "mlp_forward_sample: null pointer");
     if (n <= 0) return fail(FLY_E_ARG, "mlp_forward_sample: n must be > 0");
-    hipError_t e = flyhip_launch_mlp_forward_sample(params, params_frag, x, n, eps, var, act_out, logp_out, mu_out, stream);
+    hipError_t e = flyhip_launch_mlp_forward_sample(params, params_frag, x, n, eps, var, act_out, logp_out, mu_out, v_out, stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_forward_sample launch");
     return FLY_OK;
 }

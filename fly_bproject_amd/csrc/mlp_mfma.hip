@@ -260,6 +260,9 @@ __global__ __launch_bounds__(THREADS, 3) void mlp_forward_kernel(
         if (STAMP && threadIdx.x == 0) {
             unsigned long long t;
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+            // top 16 bits: which CU this workgroup landed on (HW_ID cu/sh/se bits 8..15, XCC_ID)
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+            t = (t & 0xffffffffffffull) | ((unsigned long long)(((hw >> 8) & 0xff) | ((xcc & 0xf) << 8)) << 48);
             stamps[(long)blockIdx.x * 16 + 14] = t;
         }
         x_store(tl);
@@ -934,12 +937,12 @@ extern "C" hipError_t flyhip_launch_mlp_forward(const float* P, const float* PF,
 
 extern "C" hipError_t flyhip_launch_mlp_forward_sample(const float* P, const float* PF, const float* x, int64_t n,
                                                        const float* eps, const float* var, float* act_out,
-                                                       float* logp_out, float* mu_out, void* stream)
+                                                       float* logp_out, float* mu_out, float* v_out, void* stream)
 {
     const long tiles = (n + BM - 1) / BM;
     const int grid = (int)(tiles <= 4 * 768 ? tiles : 768);
     hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PF, x, (long)n,
-                       mu_out, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, eps,
+                       mu_out, v_out, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, eps,
                        var, act_out, logp_out, (unsigned long long*)nullptr);
     return hipGetLastError();
 }

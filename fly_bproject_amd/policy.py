@@ -114,8 +114,10 @@ class PackedPolicy:
         with torch.no_grad():
             self.PF[self._dst_f] = self.P[self._src_f]
             self.PT[self._dst_t] = self.P[self._src_t]
+        self.version += 1
 
     refresh_transposes = refresh
+    version = 0         # bumped whenever the weights change: consumers of cached network outputs compare it
 
     def forward(self, x, want_mu=True, want_v=True, saves=None):
         """x f32 [..., 73] on the device -> (mu [..., 18] | None, v [..., 1] | None)."""
@@ -182,6 +184,7 @@ class PackedPolicy:
 
     def adam_step(self, grad_scale=1.0, norm_ready=False):
         p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+        self.version += 1
         _lib.check(self._lib.mlp_adam_step(p(self.P), p(self.PF), p(self.PT), p(self.idx_f), p(self.idx_t), p(self.G),
                                            p(self.grad_mask), p(self.exp_avg),
                                            p(self.exp_avg_sq), p(self.step), C.c_float(self.lr),

@@ -93,6 +93,11 @@ class PPO:
         self._obs_ring = torch.zeros((T + 1, n, self.num_obs), device=dev)
         self.all_obs = self._obs_ring[:T]
         self.all_next_obs = self._obs_ring[1:]
+        # v(obs_t) falls out of the rollout's policy launch (same kernel, same weights, same rows as the
+        # critic pass of ppo.py:158-159), so make_data only has to evaluate the last next_obs
+        self._v_ring = torch.zeros((T + 1, n, 1), device=dev)
+        self._v_have, self._v_version = 0, -1
+        self.reuse_rollout_values = bool(getattr(args, "reuse_rollout_values", True))
         self.all_acts = torch.zeros((T, n, self.num_acts), device=dev)
         self.all_reward = torch.zeros((T, n, 1), device=dev)
         self._all_done = None                                        # see the all_done property (Q1)
@@ -161,7 +166,12 @@ class PPO:
         broadcast over T (Q1), and the recurrence never resets at episode ends (Q2)."""
         T, n = self.rollout_size, self.args.num_envs
         with torch.no_grad():
-            values = self.net.v(self._obs_ring)                     # [T+1, N, 1]: v(obs) and v(next_obs) in one pass
+            if self.reuse_rollout_values and self._v_have == T and self._v_version == self.policy.version:
+                self._v_ring[T].copy_(self.net.v(self._obs_ring[T]))
+                values = self._v_ring                               # rows 0..T-1 were written by the rollout launches
+            else:
+                values = self.net.v(self._obs_ring)                 # [T+1, N, 1]: v(obs) and v(next_obs) in one pass
+            self._v_have = 0
             done = self.all_done
             per_step = done.dim() == 3 and done.shape[0] == T and done.shape[1] == n
             mode = 1 if per_step else 0                             # reference path: [N,1]
@@ -275,7 +285,7 @@ class PPO:
         for t in range(T):
             fwd.append((P(pol.P.data_ptr()), P(pol.PF.data_ptr()), P(self._obs_rows[t].data_ptr()), C.c_int64(n),
                         P(self._eps_all[t].data_ptr()), P(self.action_var.data_ptr()), P(self._act_rows[t].data_ptr()),
-                        P(self.all_log_prob[t].data_ptr()), None))
+                        P(self.all_log_prob[t].data_ptr()), None, P(self._v_ring[t].data_ptr())))
             book.append((P(self._reward_rows[t].data_ptr()), C.c_int64(n), P(self._score_acc.data_ptr()),
                          C.c_float(1.0 / self.num_eval_freq), P(self.action_var.data_ptr()), C.c_int(self.num_acts)))
             bufs.append((self._obs_rows[t + 1].data_ptr(), self._reward_rows[t].data_ptr()))
@@ -290,6 +300,10 @@ class PPO:
         if t == 0:
             self._eps_all.normal_(generator=self._gen)              # the eps of MultivariateNormal.sample, whole rollout
         rc = lib.mlp_forward_sample(*self._fwd_args[t], st)         # ppo.py:214-220, :227 (policy + sampling fused)
+        if t == 0:
+            self._v_have, self._v_version = 1, self.policy.version
+        elif self._v_have == t:
+            self._v_have = t + 1
         env.obs_buf, env.reward_buf = self._obs_rows[t + 1], self._reward_rows[t]      # ppo.py:228-229
         env._bufs.obs, env._bufs.reward = self._buf_ptrs[t]
         rc |= lib.fly_step(env._handle, C.c_void_p(self._act_rows[t].data_ptr()), C.byref(env._bufs), st)  # ppo.py:223

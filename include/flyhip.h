@@ -206,10 +206,11 @@ int mlp_forward(const float* params, const float* params_frag, const float* x, i
                 float* out_save, float* h1_save, float* h2_save, float* h3_save, void* stream);
 /* ppo.py:214-220 in ONE launch: mu = Net.pi(x), act = mu + sqrt(var)*eps, log-prob of the unclipped
  * act, act_out = clip(act, -1, 1).  eps, act_out f32 [n][18]; var f32 [18]; logp_out f32 [n];
- * mu_out f32 [n][18] optional. */
+ * mu_out f32 [n][18] and v_out f32 [n] (= Net.v(x), the same rows the critic pass of ppo.py:158-159
+ * would recompute with unchanged weights) are optional. */
 int mlp_forward_sample(const float* params, const float* params_frag, const float* x, int64_t n,
                        const float* eps, const float* var, float* act_out, float* logp_out,
-                       float* mu_out, void* stream);
+                       float* mu_out, float* v_out, void* stream);
 
 
 /*

@@ -106,6 +106,34 @@ def test_mfma_forward_matches_torch_and_oracle(golden, n):
             assert torch.equal(net.pi(x), mu)
 
 
+def test_rollout_values_equal_the_critic_pass():
+    """make_data with v(obs_t) captured from the rollout's policy launches == make_data with the
+    reference's separate critic pass over all stored observations (ppo.py:158-159), bit for bit;
+    a weight change between rollout and make_data invalidates the captured values."""
+    from fly_bproject_amd.ppo import PPO
+    res = {}
+    for reuse in (True, False):
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            agent = PPO(make_args(4096, reuse_rollout_values=reuse))
+            _run(agent, agent.rollout_size - 1)
+            agent._launch_step(agent.rollout_size - 1)           # last step without the update
+        assert agent._v_have == (agent.rollout_size)
+        _, _, _, target, adv = agent.make_data()
+        torch.cuda.synchronize()
+        res[reuse] = (target.clone(), adv.clone())
+        if reuse:
+            with torch.no_grad():
+                full = agent.net.v(agent._obs_ring)
+            assert torch.equal(full, agent._v_ring)
+            agent._v_have = agent.rollout_size                   # pretend the rollout is still cached ...
+            agent.policy.P.mul_(1.001); agent.policy.refresh()   # ... but the weights moved
+            _, _, _, t2, _ = agent.make_data()
+            assert not torch.equal(t2, res[True][0])
+        agent.exit()
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+
+
 def test_graph_replay_matches_eager_rollout():
     """Rollout steps replayed from captured hipGraphs leave exactly what the eager launches leave
     (same seeds; the captured normal_ advances the Philox offset like the eager call)."""
@@ -144,13 +172,14 @@ def test_fused_forward_sample_matches_separate_kernels(n):
     eps = torch.randn(n, 18, device="cuda:0")
     var = torch.rand(18, device="cuda:0") * 0.19 + 0.01
     p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
-    mu, _ = pol.forward(x, want_mu=True, want_v=False)
+    mu, v1 = pol.forward(x, want_mu=True, want_v=True)
     act1 = torch.empty(n, 18, device="cuda:0"); lp1 = torch.empty(n, device="cuda:0")
     _lib.check(lib.ppo_sample_logprob(p(mu), p(var), p(eps), p(act1), p(lp1), n, None), "sample")
     act2 = torch.empty(n, 18, device="cuda:0"); lp2 = torch.empty(n, device="cuda:0"); mu2 = torch.empty(n, 18, device="cuda:0")
-    _lib.check(lib.mlp_forward_sample(p(pol.P), p(pol.PF), p(x), n, p(eps), p(var), p(act2), p(lp2), p(mu2), None), "fused")
+    v2 = torch.empty(n, device="cuda:0")
+    _lib.check(lib.mlp_forward_sample(p(pol.P), p(pol.PF), p(x), n, p(eps), p(var), p(act2), p(lp2), p(mu2), p(v2), None), "fused")
     torch.cuda.synchronize()
-    assert torch.equal(mu, mu2) and torch.equal(act1, act2)
+    assert torch.equal(mu, mu2) and torch.equal(act1, act2) and torch.equal(v1.view(-1), v2)
     torch.testing.assert_close(lp1, lp2, rtol=2e-6, atol=1e-5)
     a_o, lp_o = O.sample_logprob(mu.cpu().numpy(), var.cpu().numpy(), eps.cpu().numpy())
     assert np.array_equal(act2.cpu().numpy(), a_o)

@@ -30,6 +30,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 raw = stamps.cpu().numpy().reshape(grid, 16).astype(np.int64)
 raw = raw[raw[:, 13] > 0]                      # workgroups that stamped (persistent grids are smaller)
+cu = (raw[:, 14] >> 48) & 0xfff                # xcc(4) | se(3) sh(1) cu(4)
+raw[:, 14] &= (1 << 48) - 1
 grid = raw.shape[0]
 st = raw[:, :14]
 real = (raw[:, 15] - raw[:, 14]).astype(np.float64)          # 100 MHz ticks
@@ -45,3 +47,24 @@ for i, nm in enumerate(names):
     print("%-22s mean %8.0f  median %8.0f  (%4.1f %%)" % (nm, d[:, i].mean(), np.median(d[:, i]), 100 * d[:, i].mean() / tot.mean()))
 rt = raw[:, 15].max() - raw[:, 14].min()
 print("first start -> last end (s_memrealtime, global): %.2f us" % (rt / 100.0))
+t0 = raw[:, 14].min()
+start = (raw[:, 14] - t0) / 100.0
+end = (raw[:, 15] - t0) / 100.0
+first = start < 0.5 * np.median(end - start)
+print("first-round workgroups %d: mean duration %.2f us; later workgroups %d: mean duration %.2f us, start mean %.2f us (p10 %.2f, p90 %.2f)" %
+      (first.sum(), (end - start)[first].mean(), (~first).sum(), (end - start)[~first].mean(), start[~first].mean(),
+       np.percentile(start[~first], 10), np.percentile(start[~first], 90)))
+ncu = len(np.unique(cu))
+per_cu = np.bincount(np.unique(cu, return_inverse=True)[1])
+print("distinct CUs seen %d; workgroups per CU: min %d max %d; histogram %s" % (ncu, per_cu.min(), per_cu.max(), np.bincount(per_cu).tolist()))
+last_end = np.array([end[cu == c].max() for c in np.unique(cu)])
+print("per-CU finish time: mean %.2f us, p10 %.2f, p90 %.2f, max %.2f" % (last_end.mean(), np.percentile(last_end, 10), np.percentile(last_end, 90), last_end.max()))
+xcc = cu >> 8
+print("workgroups per XCC:", np.bincount(xcc).tolist())
+dur = end - start
+print("first-round duration percentiles (us): p5 %.1f p25 %.1f p50 %.1f p75 %.1f p95 %.1f" % tuple(np.percentile(dur[first], [5, 25, 50, 75, 95])))
+print("later-round duration percentiles (us): p5 %.1f p25 %.1f p50 %.1f p75 %.1f p95 %.1f" % tuple(np.percentile(dur[~first], [5, 25, 50, 75, 95])))
+for c in np.unique(cu)[:6]:
+    m = cu == c
+    o = np.argsort(start[m])
+    print("CU %03x:" % c, " ".join("[%.1f-%.1f]" % (a, b) for a, b in zip(start[m][o], end[m][o])))
