@@ -5,7 +5,7 @@ import os
 from .params import FlyParams
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libflyhip.so")
+LIB_PATH = os.environ.get("FLYHIP_LIB") or os.path.join(_HERE, "libflyhip.so")
 _lib = None
 
 
@@ -40,6 +40,7 @@ SYMBOLS = {
     "mlp_forward_sample": [_P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P],
     "mlp_grad_workspace_floats": [],
     "mlp_backward_dx": [_P] * 10 + [_L, _F, _F, _P, _P, _P, _P, _P, _P],
+    "mlp_forward_backward": [_P] * 4 + [_L] + [_P] * 9 + [_F, _F] + [_P] * 6 + [_I, _P, _P],
     "mlp_grad_w": [_P] * 8 + [_L, _P, _P, _P, _P, _P, _P],
     "mlp_adam_step": [_P] * 10 + [_F, _F, _F, _F, _F, _F, _P, _I, _P],
     "dqn_eps_greedy": [_P, _P, _P, _F, _I, _P, _L, _P],

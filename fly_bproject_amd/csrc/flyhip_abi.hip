@@ -51,6 +51,12 @@ extern "C" hipError_t flyhip_launch_mlp_forward_sample(const float* P, const flo
                                                        const float* eps, const float* var, float* act_out,
                                                        float* logp_out, float* mu_out, float* v_out, void* stream);
 
+extern "C" hipError_t flyhip_launch_mlp_fwd_bwd(const float* P, const float* PF, const float* PT, const float* x, int64_t n,
+                                                float* out_save, float* h1_save, float* h2_save, float* h3_save,
+                                                const float* action, const float* old_logp, const float* adv,
+                                                const float* target, const float* var, float inv_batch, float clip,
+                                                float* dz4, float* dz3, float* dz2, float* dz1, float* loss_part,
+                                                int* flags, int epoch, int* err, void* stream);
 extern "C" hipError_t flyhip_launch_adv_stats(const float* adv, int64_t n, float* stats, void* stream);
 extern "C" hipError_t flyhip_launch_adv_apply(float* adv, int64_t n, const float* totals, float count, float eps, void* stream);
 
@@ -258,6 +264,25 @@ int mlp_backward_dx(const float* params_t, const float* out_saved, const float* 
                                                  adv, target, var, n, inv_batch, clip, dz4, dz3, dz2, dz1, loss_part,
                                                  stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_backward_dx launch");
+    return FLY_OK;
+}
+
+int mlp_forward_backward(const float* params, const float* params_frag, const float* params_t_frag,
+                         const float* x, int64_t n, float* out_save, float* h1_save, float* h2_save,
+                         float* h3_save, const float* action, const float* old_logp, const float* adv,
+                         const float* target, const float* var, float inv_batch, float clip,
+                         float* dz4, float* dz3, float* dz2, float* dz1, float* loss_part,
+                         int32_t* flags, int32_t epoch, int32_t* err, void* stream)
+{
+    if (!params || !params_frag || !params_t_frag || !x || !out_save || !h1_save || !h2_save || !h3_save || !action ||
+        !old_logp || !adv || !target || !var || !dz4 || !dz3 || !dz2 || !dz1 || !flags || !err)
+        return fail(FLY_E_ARG, "mlp_forward_backward: null pointer");
+    if (n <= 0) return fail(FLY_E_ARG, "mlp_forward_backward: n must be > 0");
+    if (epoch <= 0 || epoch >= (1 << 27)) return fail(FLY_E_ARG, "mlp_forward_backward: epoch must be in [1, 2^27)");
+    hipError_t e = flyhip_launch_mlp_fwd_bwd(params, params_frag, params_t_frag, x, n, out_save, h1_save, h2_save, h3_save,
+                                             action, old_logp, adv, target, var, inv_batch, clip, dz4, dz3, dz2, dz1,
+                                             loss_part, flags, epoch, err, stream);
+    if (e != hipSuccess) return hip_fail(e, "mlp_forward_backward launch");
     return FLY_OK;
 }
 

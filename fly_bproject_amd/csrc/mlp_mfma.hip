@@ -46,9 +46,26 @@ __device__ __forceinline__ float elu_grad_from_out(float y) { return y > 0.0f ? 
 //   Wf     : this layer's weights in fragment order (mlp_layout.h): [col tile][K/8][64 lanes][4];
 //            `tile0` = first column tile of this wave.  One wave-instruction = one contiguous KiB.
 // k mapping: MFMA step s = 4*kq+q multiplies k = 4*kq+q (lanes 0..31) and k = K/2+4*kq+q (32..63).
+// The first two weight k-quads of a GEMM, requested AHEAD of it: a caller issues `gemm_prefetch`
+// before the previous layer's epilogue / barrier / copy-out so the L2 round trip (1-2 k cycles,
+// once per layer per tile) hides under that work instead of opening every MFMA loop.
+template <int NT>
+struct WeightHead { float4 b0[NT], b1[NT]; };
+
 template <int K, int NT>
-__device__ __forceinline__ void tile_gemm(const float* __restrict__ Wf, int tile0, const float* lds_in,
-                                          f32x16 (&acc)[NT], int lane)
+__device__ __forceinline__ void gemm_prefetch(WeightHead<NT>& w, const float* __restrict__ Wf, int tile0, int lane)
+{
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float* bp = Wf + (long)(tile0 + t) * (K / 8) * 256 + lane * 4;
+        w.b0[t] = *reinterpret_cast<const float4*>(bp);
+        w.b1[t] = *reinterpret_cast<const float4*>(bp + 256);
+    }
+}
+
+template <int K, int NT>
+__device__ __forceinline__ void tile_gemm(const WeightHead<NT>& head, const float* __restrict__ Wf, int tile0,
+                                          const float* lds_in, f32x16 (&acc)[NT], int lane)
 {
     const int r = lane & 31, h = lane >> 5;
     const float* ap = lds_in + r * (K + 4) + h * (K / 2);
@@ -62,8 +79,8 @@ __device__ __forceinline__ void tile_gemm(const float* __restrict__ Wf, int tile
     float4 b0[NT], b1[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        b0[t] = *reinterpret_cast<const float4*>(bp[t]);
-        b1[t] = *reinterpret_cast<const float4*>(bp[t] + 256);
+        b0[t] = head.b0[t];
+        b1[t] = head.b1[t];
     }
     float4 a0 = *reinterpret_cast<const float4*>(ap);
 #pragma unroll 1
@@ -106,18 +123,32 @@ __device__ __forceinline__ void tile_gemm(const float* __restrict__ Wf, int tile
     }
 }
 
+template <int K, int NT>
+__device__ __forceinline__ void tile_gemm(const float* __restrict__ Wf, int tile0, const float* lds_in,
+                                          f32x16 (&acc)[NT], int lane)
+{
+    WeightHead<NT> head;
+    gemm_prefetch<K, NT>(head, Wf, tile0, lane);
+    tile_gemm<K, NT>(head, Wf, tile0, lds_in, acc, lane);
+}
+
 // C/D layout of the 32x32 tile with the operand roles above: lane holds row (lane&31) and output
 // columns n = 8*g + 4*(lane>>5) + j for register 4*g + j.
 __device__ __forceinline__ int acc_n(int g, int lane) { return 8 * g + 4 * (lane >> 5); }
 // generic C/D map (A operand indexes rows): row (reg&3) + 8*(reg>>2) + 4*(lane>>5), column lane&31
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-// bias + ELU epilogue: writes the activation tile to LDS (the next layer's operand), 16 bytes per store.
+// bias + ELU epilogue: writes the activation tile to LDS (the next layer's operand), 16 bytes per
+// store, and -- when `gdst` is given -- the same 16 bytes to the saved-activation rows in HBM.  A
+// wave's four stores of one column tile touch the same 32 lines (one 128-byte line per row) and
+// together fill them, so L2 merges them into full-line writes; no LDS read-back pass is needed.
 template <int N, int NT>
 __device__ __forceinline__ void epilogue_elu(const f32x16 (&acc)[NT], const float* __restrict__ bias, int col0,
-                                             float* lds_out, int lane)
+                                             float* lds_out, int lane, float* __restrict__ gdst, long row0, long nrows)
 {
     const int r = lane & 31;
+    const bool st = gdst != nullptr && row0 + r < nrows;
+    float* grow = gdst + (row0 + r) * N;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -130,24 +161,8 @@ __device__ __forceinline__ void epilogue_elu(const f32x16 (&acc)[NT], const floa
             y.z = elu(acc[t][4 * g + 2] + bv.z);
             y.w = elu(acc[t][4 * g + 3] + bv.w);
             *reinterpret_cast<float4*>(lds_out + r * (N + 4) + nb) = y;
+            if (st) *reinterpret_cast<float4*>(grow + nb) = y;
         }
-    }
-}
-
-// Copy a finished [32][N] tile from LDS (pitch N+4) to global [rows][N]: the tile is one contiguous
-// block of 32*N floats in HBM, written with 16-byte stores by the whole workgroup.
-template <int N>
-__device__ __forceinline__ void copy_tile_out(const float* lds_tile, float* __restrict__ dst, long row0, long nrows, int tid)
-{
-    if (!dst) return;
-    static_assert((BM * N / 4) % THREADS == 0, "whole float4 rounds");
-#pragma unroll
-    for (int u = 0; u < BM * N / 4 / THREADS; ++u) {
-        const int i = tid + u * THREADS;
-        const int row = i / (N / 4), c4 = i - row * (N / 4);
-        if (row0 + row < nrows)
-            *reinterpret_cast<float4*>(dst + (row0 + row) * N + 4 * c4) =
-                *reinterpret_cast<const float4*>(lds_tile + row * (N + 4) + 4 * c4);
     }
 }
 
@@ -162,6 +177,8 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NT])
 
 constexpr int LDS_A_FLOATS = BM * (MLP_H1 + 4);      // H1, later H3
 constexpr int LDS_B_FLOATS = BM * (MLP_H2 + 4);      // X0, later H2, later the split-K partials
+constexpr int LB1 = 0, LB2 = MLP_H1, LB3 = LB2 + MLP_H2, LB4 = LB3 + MLP_H3, LSD = LB4 + MLP_OUT, LLG = LSD + 32;
+constexpr int LDS_C_FLOATS = LLG + 32;               // biases + sampling constants (2.4 KB)
 
 // In-kernel phase stamps (diagnostic instantiation only, tools/stamp_forward.py; the shipped
 // instantiation compiles them out): wave 0 / lane 0 of each workgroup stores s_memtime at the phase
@@ -173,7 +190,7 @@ __device__ __forceinline__ void stamp(unsigned long long* buf, int slot)
         if (threadIdx.x == 0) {
             unsigned long long t;
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-            buf[(long)blockIdx.x * 16 + slot] = t;
+            buf[slot] = t;
         }
     }
 }
@@ -186,17 +203,23 @@ __device__ __forceinline__ void stamp(unsigned long long* buf, int slot)
 // computes, so the ~5 us HBM round trip that used to open every workgroup is hidden.
 constexpr int XV = (BM * MLP_IN / 4 + THREADS - 1) / THREADS;       // float4 per thread for one x tile (584 / 256 -> 3)
 
+constexpr int FWD_LDS_FLOATS = LDS_A_FLOATS + LDS_B_FLOATS + LDS_C_FLOATS;
+
+// The body walks tiles first_tile, first_tile + tile_stride, ... (< ntiles) on the caller's LDS
+// arena; `slot` is the de-phasing delay of this workgroup (see below).
 template <bool STAMP>
-__global__ __launch_bounds__(THREADS, 3) void mlp_forward_kernel(
+__device__ __forceinline__ void forward_body(
+    float* lds, const long first_tile, const long tile_stride, const int slot,
     const float* __restrict__ P, const float* __restrict__ PF, const float* __restrict__ x, long n,
     float* __restrict__ mu_out, float* __restrict__ v_out, float* __restrict__ out_save,
     float* __restrict__ h1_save, float* __restrict__ h2_save, float* __restrict__ h3_save,
     const float* __restrict__ smp_eps, const float* __restrict__ smp_var, float* __restrict__ smp_act,
-    float* __restrict__ smp_logp, unsigned long long* __restrict__ stamps)
+    float* __restrict__ smp_logp, unsigned long long* __restrict__ stamps_base)
 {
-    __shared__ __attribute__((aligned(16))) float lds[LDS_A_FLOATS + LDS_B_FLOATS];
+    unsigned long long* stamps = stamps_base;
     float* ldsA = lds;
     float* ldsB = lds + LDS_A_FLOATS;
+    float* ldsBias = ldsB + LDS_B_FLOATS;   // b1 | b2 | b3 | b4 | sqrt(var) | log sqrt(var): read by every epilogue
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long ntiles = (n + BM - 1) / BM;
     const long total = n * MLP_IN;
@@ -244,18 +267,27 @@ __global__ __launch_bounds__(THREADS, 3) void mlp_forward_kernel(
     // epilogues together (matrix pipe idle).  Workgroups b, b+256, b+512 are the ones the dispatcher
     // co-locates first; delaying the second and third by one and two thirds of a tile's solo time
     // lets one group's epilogue hide under the others' MFMAs.  Speed only, never correctness.
-    {
-        const int slot = (blockIdx.x >> 8) % 3;
-        for (int i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(127);     // 127 * 64 cycles each
-    }
-    long tile = blockIdx.x;
+    for (int i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(127);     // 127 * 64 cycles each
+    long tile = first_tile;
     if (tile < ntiles) x_load(tile);
-    for (; tile < ntiles; tile += gridDim.x) {
+    {   // biases (and the sampling constants) -> LDS once per workgroup; the first tile's barrier publishes them
+        ldsBias[LB1 + tid] = P[MLP_OFF_B1 + tid];
+        if (tid < MLP_H2) ldsBias[LB2 + tid] = P[MLP_OFF_B2 + tid];
+        else ldsBias[LB3 + tid - MLP_H2] = P[MLP_OFF_B3 + tid - MLP_H2];
+        if (tid < MLP_OUT) ldsBias[LB4 + tid] = P[MLP_OFF_B4 + tid];
+        if (smp_var && tid >= 64 && tid < 64 + MLP_NACT) {
+            const float L = sqrtf(smp_var[tid - 64]);
+            ldsBias[LSD + tid - 64] = L;
+            ldsBias[LLG + tid - 64] = logf(L);
+        }
+    }
+    for (; tile < ntiles; tile += tile_stride) {
         const long row0 = tile * BM;
         // opaque per-iteration copy of the thread index: keeps the dozens of tile-invariant LDS/global
         // offsets from being hoisted out of the tile loop (they would all be live across it and spill)
         int tl = tid;
         asm volatile("" : "+v"(tl));
+        if (STAMP) stamps = stamps_base + tile * 16;         // one 16-slot record per tile
         stamp<STAMP>(stamps, 0);
         if (STAMP && threadIdx.x == 0) {
             unsigned long long t;
@@ -263,58 +295,63 @@ __global__ __launch_bounds__(THREADS, 3) void mlp_forward_kernel(
             // top 16 bits: which CU this workgroup landed on (HW_ID cu/sh/se bits 8..15, XCC_ID)
             const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
             t = (t & 0xffffffffffffull) | ((unsigned long long)(((hw >> 8) & 0xff) | ((xcc & 0xf) << 8)) << 48);
-            stamps[(long)blockIdx.x * 16 + 14] = t;
+            stamps[14] = t;
         }
+        WeightHead<2> w1;
+        gemm_prefetch<MLP_IN_PAD, 2>(w1, PF + MLP_OFF_F1, wave * 2, lane);    // lands during the x staging
         x_store(tl);
         __syncthreads();
-        if (tile + gridDim.x < ntiles) x_load(tile + gridDim.x);     // lands during this tile's MFMAs
+        if (tile + tile_stride < ntiles) x_load(tile + tile_stride);     // lands during this tile's MFMAs
         stamp<STAMP>(stamps, 1);
+        WeightHead<1> w2, w3;
         {   // L1: 80 -> 256, wave owns 64 columns
             f32x16 acc[2];
             zero_acc(acc);
-            tile_gemm<MLP_IN_PAD, 2>(PF + MLP_OFF_F1, wave * 2, ldsB, acc, lane);
+            tile_gemm<MLP_IN_PAD, 2>(w1, PF + MLP_OFF_F1, wave * 2, ldsB, acc, lane);
             stamp<STAMP>(stamps, 2);
-            epilogue_elu<MLP_H1, 2>(acc, P + MLP_OFF_B1, wave * 64, ldsA, lane);
+            gemm_prefetch<MLP_H1, 1>(w2, PF + MLP_OFF_F2, wave, lane);        // lands during epilogue + copy-out
+            epilogue_elu<MLP_H1, 2>(acc, ldsBias + LB1, wave * 64, ldsA, lane, h1_save, row0, n);
         }
         stamp<STAMP>(stamps, 3);
         __syncthreads();
         stamp<STAMP>(stamps, 4);
-        copy_tile_out<MLP_H1>(ldsA, h1_save, row0, n, tl);
         stamp<STAMP>(stamps, 5);
         {   // L2: 256 -> 128, wave owns 32 columns
             f32x16 acc[1];
             zero_acc(acc);
-            tile_gemm<MLP_H1, 1>(PF + MLP_OFF_F2, wave, ldsA, acc, lane);
+            tile_gemm<MLP_H1, 1>(w2, PF + MLP_OFF_F2, wave, ldsA, acc, lane);
             stamp<STAMP>(stamps, 6);
-            epilogue_elu<MLP_H2, 1>(acc, P + MLP_OFF_B2, wave * 32, ldsB, lane);
+            gemm_prefetch<MLP_H2, 1>(w3, PF + MLP_OFF_F3, wave, lane);
+            epilogue_elu<MLP_H2, 1>(acc, ldsBias + LB2, wave * 32, ldsB, lane, h2_save, row0, n);
         }
         stamp<STAMP>(stamps, 7);
         __syncthreads();
         stamp<STAMP>(stamps, 8);
-        copy_tile_out<MLP_H2>(ldsB, h2_save, row0, n, tl);
+        float4 w4[4];                                                            // layer-4 weights of this wave's k range
         {   // L3: 128 -> 128 (actor | critic heads stacked)
             f32x16 acc[1];
             zero_acc(acc);
             stamp<STAMP>(stamps, 9);
-            tile_gemm<MLP_H2, 1>(PF + MLP_OFF_F3, wave, ldsB, acc, lane);
+            tile_gemm<MLP_H2, 1>(w3, PF + MLP_OFF_F3, wave, ldsB, acc, lane);
             stamp<STAMP>(stamps, 10);
-            epilogue_elu<MLP_H3, 1>(acc, P + MLP_OFF_B3, wave * 32, ldsA, lane);
+            const float* bp = PF + MLP_OFF_F4 + (wave * 4) * 256 + lane * 4;    // [wave][kq][lane][4]
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) w4[kq] = *reinterpret_cast<const float4*>(bp + 256 * kq);
+            epilogue_elu<MLP_H3, 1>(acc, ldsBias + LB3, wave * 32, ldsA, lane, h3_save, row0, n);
         }
         stamp<STAMP>(stamps, 11);
         __syncthreads();
         stamp<STAMP>(stamps, 12);
-        copy_tile_out<MLP_H3>(ldsA, h3_save, row0, n, tl);
         {   // L4: 128 -> 32, split-K over the four waves (32 k each), partials reduced through LDS
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
             const int r = lane & 31, h = lane >> 5;
             const float* ap = ldsA + r * (MLP_H3 + 4) + wave * 32 + h * 16;
-            const float* bp = PF + MLP_OFF_F4 + (wave * 4) * 256 + lane * 4;    // [wave][kq][lane][4]
 #pragma unroll
             for (int kq = 0; kq < 4; ++kq) {
                 const float4 a = *reinterpret_cast<const float4*>(ap + 4 * kq);
-                const float4 b = *reinterpret_cast<const float4*>(bp + 256 * kq);
+                const float4 b = w4[kq];
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc, 0, 0, 0);
@@ -330,7 +367,7 @@ __global__ __launch_bounds__(THREADS, 3) void mlp_forward_kernel(
         for (int i = tl; i < BM * MLP_OUT; i += THREADS) {
             const int row = i >> 5, col = i & 31;
             float z = ((ldsB[i] + ldsB[BM * MLP_OUT + i]) + ldsB[2 * BM * MLP_OUT + i]) + ldsB[3 * BM * MLP_OUT + i];
-            z += P[MLP_OFF_B4 + col];
+            z += ldsBias[LB4 + col];
             float y = (col < MLP_NACT) ? elu(z) : ((col == MLP_NACT) ? z : 0.0f);   // ELU on the mean (ppo.py:30), none on v
             const long grow = row0 + row;
             if (grow < n) {
@@ -345,11 +382,11 @@ __global__ __launch_bounds__(THREADS, 3) void mlp_forward_kernel(
                 float x2 = 0.0f, lg = 0.0f, a = 0.0f;
                 const bool on = (col < MLP_NACT) && (grow < n);
                 if (on) {
-                    const float L = sqrtf(smp_var[col]);
+                    const float L = ldsBias[LSD + col];
                     a = y + L * smp_eps[grow * MLP_NACT + col];
                     const float xj = (a - y) / L;
                     x2 = xj * xj;
-                    lg = logf(L);
+                    lg = ldsBias[LLG + col];
                 }
 #pragma unroll
                 for (int o = 1; o < 32; o <<= 1) { x2 += __shfl_xor(x2, o, 32); lg += __shfl_xor(lg, o, 32); }
@@ -361,10 +398,23 @@ __global__ __launch_bounds__(THREADS, 3) void mlp_forward_kernel(
         if (STAMP && threadIdx.x == 0) {
             unsigned long long t;
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-            stamps[(long)blockIdx.x * 16 + 15] = t;
+            stamps[15] = t;
         }
         __syncthreads();            // ldsB (partials) is the next tile's input buffer
     }
+}
+
+template <bool STAMP>
+__global__ __launch_bounds__(THREADS, 3) void mlp_forward_kernel(
+    const float* __restrict__ P, const float* __restrict__ PF, const float* __restrict__ x, long n,
+    float* __restrict__ mu_out, float* __restrict__ v_out, float* __restrict__ out_save,
+    float* __restrict__ h1_save, float* __restrict__ h2_save, float* __restrict__ h3_save,
+    const float* __restrict__ smp_eps, const float* __restrict__ smp_var, float* __restrict__ smp_act,
+    float* __restrict__ smp_logp, unsigned long long* __restrict__ stamps_base)
+{
+    __shared__ __attribute__((aligned(16))) float lds[FWD_LDS_FLOATS];
+    forward_body<STAMP>(lds, blockIdx.x, gridDim.x, (blockIdx.x >> 8) % 3, P, PF, x, n, mu_out, v_out, out_save, h1_save,
+                        h2_save, h3_save, smp_eps, smp_var, smp_act, smp_logp, stamps_base);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -377,57 +427,165 @@ __global__ __launch_bounds__(THREADS, 3) void mlp_forward_kernel(
 //   dz4 [n][32]: cols 0..17 d/d(pre-ELU mean), col 18 d/d(value), rest 0
 //   dz3 [n][128], dz2 [n][128], dz1 [n][256]: gradients at the pre-activations of layers 3,2,1
 //   loss_part [grid][2]: per-workgroup sums of the policy term and of the Huber term
-// dZ = dA * ELU'(H), in place on the LDS tile that holds H (pitch N+4): the lane that owns four
-// consecutive accumulator columns of its row reads H there as one float4 and overwrites it with dZ.
-__device__ __forceinline__ void epilogue_dact_inplace(const f32x16& acc, int col0, int N, float* lds_tile, int lane)
+// dZ = dA * ELU'(H).  H is read from the saved activations in exactly the accumulator layout (a
+// lane owns row lane&31 and four consecutive columns per register group): one 16-byte load per
+// group, requested before the GEMM whose epilogue consumes it.  The four loads of a column tile
+// touch one 128-byte line per row, so L1 serves three of them.
+template <int NT>
+struct HFrag { float4 v[NT][4]; };
+
+template <int N, int NT>
+__device__ __forceinline__ void hfrag_load(HFrag<NT>& hf, const float* __restrict__ hsrc, long row0, long nrows, int col0,
+                                           int lane)
+{
+    const long grow = row0 + (lane & 31);
+    const bool in = grow < nrows;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            hf.v[t][g] = in ? *reinterpret_cast<const float4*>(hsrc + grow * N + col0 + 32 * t + acc_n(g, lane))
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// writes dZ to the gradient rows in HBM and (lds_out != nullptr) to the LDS tile the next GEMM reads
+template <int N, int NT>
+__device__ __forceinline__ void epilogue_dact(const f32x16 (&acc)[NT], const HFrag<NT>& hf, int col0, float* lds_out,
+                                              float* __restrict__ gdst, long row0, long nrows, int lane)
 {
     const int r = lane & 31;
+    const bool st = row0 + r < nrows;
+    float* grow = gdst + (row0 + r) * N;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        float4* p = reinterpret_cast<float4*>(lds_tile + r * (N + 4) + col0 + acc_n(g, lane));
-        float4 hv = *p;
-        hv.x = acc[4 * g + 0] * elu_grad_from_out(hv.x);
-        hv.y = acc[4 * g + 1] * elu_grad_from_out(hv.y);
-        hv.z = acc[4 * g + 2] * elu_grad_from_out(hv.z);
-        hv.w = acc[4 * g + 3] * elu_grad_from_out(hv.w);
-        *p = hv;
-    }
-}
-
-// global [rows][N] tile (contiguous 32*N floats) -> registers -> LDS tile (pitch N+4), 16-byte moves
-template <int N>
-struct TileRegs { float4 v[(BM * N / 4 + THREADS - 1) / THREADS]; };
-
-template <int N>
-__device__ __forceinline__ void tile_load(TileRegs<N>& t, const float* __restrict__ src, long row0, long nrows, int tid)
-{
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
-    for (int u = 0; u < (BM * N / 4 + THREADS - 1) / THREADS; ++u) {
-        const int i = tid + u * THREADS;
-        const int row = i / (N / 4), c4 = i - row * (N / 4);
-        t.v[u] = (i < BM * N / 4 && row0 + row < nrows) ? *reinterpret_cast<const float4*>(src + (row0 + row) * N + 4 * c4)
-                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-}
-
-template <int N>
-__device__ __forceinline__ void tile_store_lds(const TileRegs<N>& t, float* lds_tile, int tid)
-{
-#pragma unroll
-    for (int u = 0; u < (BM * N / 4 + THREADS - 1) / THREADS; ++u) {
-        const int i = tid + u * THREADS;
-        const int row = i / (N / 4), c4 = i - row * (N / 4);
-        if (i < BM * N / 4) *reinterpret_cast<float4*>(lds_tile + row * (N + 4) + 4 * c4) = t.v[u];
+        for (int g = 0; g < 4; ++g) {
+            const int nb = col0 + 32 * t + acc_n(g, lane);
+            const float4 hv = hf.v[t][g];
+            float4 z;
+            z.x = acc[t][4 * g + 0] * elu_grad_from_out(hv.x);
+            z.y = acc[t][4 * g + 1] * elu_grad_from_out(hv.y);
+            z.z = acc[t][4 * g + 2] * elu_grad_from_out(hv.z);
+            z.w = acc[t][4 * g + 3] * elu_grad_from_out(hv.w);
+            if (lds_out) *reinterpret_cast<float4*>(lds_out + r * (N + 4) + nb) = z;
+            if (st) *reinterpret_cast<float4*>(grow + nb) = z;
+        }
     }
 }
 
 constexpr int BW_Z2 = 0;                                   // [32][132]
 constexpr int BW_Z3 = BW_Z2 + BM * (MLP_H2 + 4);           // [32][132]
 constexpr int BW_Z4 = BW_Z3 + BM * (MLP_H3 + 4);           // [32][36]
-constexpr int BW_Z1 = BW_Z3;                               // [32][260] aliases Z3|Z4|tail once they are dead
-constexpr int BW_FLOATS = BW_Z1 + BM * (MLP_H1 + 4) + BM + 8 + 24;
+constexpr int BW_TAIL = BW_Z4 + BM * (MLP_OUT + 4);        // [32][2] per-row loss terms
+constexpr int BW_FLOATS = BW_TAIL + 2 * BM;                // 38.9 KB
+constexpr int BW_WGS_PER_CU = 3;
 
-__global__ __launch_bounds__(THREADS, 3) void mlp_backward_dx_kernel(
+__device__ __forceinline__ void backward_body(
+    float* lds, const long tile, const int slot,
+    const float* __restrict__ PT, const float* __restrict__ out_saved, const float* __restrict__ h1_saved,
+    const float* __restrict__ h2_saved, const float* __restrict__ h3_saved,
+    const float* __restrict__ action, const float* __restrict__ old_logp, const float* __restrict__ adv,
+    const float* __restrict__ target, const float* __restrict__ var, long n, float inv_batch, float clip,
+    float* __restrict__ dz4, float* __restrict__ dz3, float* __restrict__ dz2, float* __restrict__ dz1,
+    float* __restrict__ loss_part)
+{
+    float* ldsZ2 = lds + BW_Z2;
+    float* ldsZ3 = lds + BW_Z3;
+    float* ldsZ4 = lds + BW_Z4;
+    float* rowloss = lds + BW_TAIL;                        // [32][2]: policy term, Huber term of each row
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long row0 = tile * BM;
+
+    // de-phase co-resident workgroups (see forward_body)
+    for (int i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(127);
+    WeightHead<1> wt4, wt3;
+    gemm_prefetch<MLP_OUT, 1>(wt4, PT + MLP_OFF_TF4, wave, lane);
+    HFrag<1> hf3;
+    hfrag_load<MLP_H3, 1>(hf3, h3_saved, row0, n, wave * 32, lane);     // in flight during the loss phase
+
+    // Loss gradient at the outputs, one thread per (row, output column): the 32 lanes of a row
+    // reduce the Mahalanobis term and log-determinant with a fixed xor butterfly, every lane then
+    // holds the row's d loss / d logp and writes its own column of dZ4 (HBM + the LDS operand).
+    {
+        const int col = tid & 31;
+        const bool act = col < MLP_NACT;
+        const float L = act ? sqrtf(var[col]) : 1.0f;
+        const float var_col = act ? var[col] : 1.0f;
+        float half_log_det = act ? logf(L) : 0.0f;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) half_log_det += __shfl_xor(half_log_det, o, 32);
+#pragma unroll
+        for (int k = 0; k < BM * MLP_OUT / THREADS; ++k) {
+            const int row = (tid >> 5) + k * (THREADS / 32);
+            const long g = row0 + row;
+            const bool in = g < n;
+            const float y = in ? out_saved[g * MLP_OUT + col] : 0.0f;                 // mean (cols 0..17), value (col 18)
+            const float a = (in && act) ? action[g * MLP_NACT + col] : 0.0f;
+            const float xj = act ? (a - y) / L : 0.0f;
+            float M = xj * xj;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) M += __shfl_xor(M, o, 32);
+            float d = 0.0f, pol = 0.0f, hub = 0.0f;
+            if (in) {
+                const float logp = -0.5f * (33.08178959434617f + M) - half_log_det;
+                const float ratio = expf(logp - old_logp[g]);
+                const float A = adv[g];
+                const float s1 = ratio * A;
+                const float rc = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+                const float s2 = rc * A;
+                const float in_range = (ratio >= 1.0f - clip && ratio <= 1.0f + clip) ? 1.0f : 0.0f;
+                float dmin;                                    // d min(s1,s2) / d ratio
+                if (s1 < s2) dmin = A;
+                else if (s1 > s2) dmin = A * in_range;
+                else dmin = 0.5f * (A + A * in_range);
+                const float c = -inv_batch * ratio * dmin;     // d loss / d logp
+                pol = -fminf(s1, s2);
+                const float dv = __shfl(y, MLP_NACT, 32) - target[g];
+                hub = fabsf(dv) < 1.0f ? 0.5f * dv * dv : fabsf(dv) - 0.5f;
+                if (act) d = c * (a - y) / var_col * elu_grad_from_out(y);
+                else if (col == MLP_NACT) d = inv_batch * fminf(fmaxf(dv, -1.0f), 1.0f);   // smooth_l1', beta = 1
+                dz4[g * MLP_OUT + col] = d;
+            }
+            ldsZ4[row * (MLP_OUT + 4) + col] = d;
+            if (col == 0) { rowloss[2 * row] = pol; rowloss[2 * row + 1] = hub; }
+        }
+    }
+    __syncthreads();
+    if (tid < 32 && loss_part) {       // fixed-order sum of the 32 rows' loss terms
+        float pol = rowloss[2 * tid], hub = rowloss[2 * tid + 1];
+        for (int o = 16; o > 0; o >>= 1) { pol += __shfl_down(pol, o, 32); hub += __shfl_down(hub, o, 32); }
+        if (tid == 0) { loss_part[2 * tile] = pol; loss_part[2 * tile + 1] = hub; }
+    }
+    HFrag<1> hf2;
+    {   // dA3 = dZ4 . W4  ->  dZ3
+        f32x16 acc[1];
+        zero_acc(acc);
+        tile_gemm<MLP_OUT, 1>(wt4, PT + MLP_OFF_TF4, wave, ldsZ4, acc, lane);
+        gemm_prefetch<MLP_H3, 1>(wt3, PT + MLP_OFF_TF3, wave, lane);          // both land during the epilogue + barrier
+        hfrag_load<MLP_H2, 1>(hf2, h2_saved, row0, n, wave * 32, lane);
+        epilogue_dact<MLP_H3, 1>(acc, hf3, wave * 32, ldsZ3, dz3, row0, n, lane);
+    }
+    __syncthreads();
+    WeightHead<2> wt2;
+    HFrag<2> hf1;
+    {   // dA2 = dZ3 . W3  ->  dZ2
+        f32x16 acc[1];
+        zero_acc(acc);
+        tile_gemm<MLP_H3, 1>(wt3, PT + MLP_OFF_TF3, wave, ldsZ3, acc, lane);
+        gemm_prefetch<MLP_H2, 2>(wt2, PT + MLP_OFF_TF2, wave * 2, lane);
+        epilogue_dact<MLP_H2, 1>(acc, hf2, wave * 32, ldsZ2, dz2, row0, n, lane);
+    }
+    __syncthreads();
+    {   // dA1 = dZ2 . W2  ->  dZ1 (no later GEMM reads it: HBM only)
+        hfrag_load<MLP_H1, 2>(hf1, h1_saved, row0, n, wave * 64, lane);       // lands during the MFMAs
+        f32x16 acc[2];
+        zero_acc(acc);
+        tile_gemm<MLP_H2, 2>(wt2, PT + MLP_OFF_TF2, wave * 2, ldsZ2, acc, lane);
+        epilogue_dact<MLP_H1, 2>(acc, hf1, wave * 64, nullptr, dz1, row0, n, lane);
+    }
+}
+
+__global__ __launch_bounds__(THREADS, BW_WGS_PER_CU) void mlp_backward_dx_kernel(
     const float* __restrict__ PT, const float* __restrict__ out_saved, const float* __restrict__ h1_saved,
     const float* __restrict__ h2_saved, const float* __restrict__ h3_saved,
     const float* __restrict__ action, const float* __restrict__ old_logp, const float* __restrict__ adv,
@@ -436,116 +594,95 @@ __global__ __launch_bounds__(THREADS, 3) void mlp_backward_dx_kernel(
     float* __restrict__ loss_part)
 {
     __shared__ __attribute__((aligned(16))) float lds[BW_FLOATS];
-    float* ldsZ2 = lds + BW_Z2;
-    float* ldsZ3 = lds + BW_Z3;
-    float* ldsZ4 = lds + BW_Z4;
-    float* ldsZ1 = lds + BW_Z1;
-    float* coef = lds + BW_Z1 + BM * (MLP_H1 + 4);        // [32] per-row d loss / d logp
-    float* red = coef + BM;                               // [8] loss partials
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long row0 = (long)blockIdx.x * BM;
+    backward_body(lds, blockIdx.x, (blockIdx.x >> 8) % BW_WGS_PER_CU, PT, out_saved, h1_saved, h2_saved, h3_saved, action,
+                  old_logp, adv, target, var, n, inv_batch, clip, dz4, dz3, dz2, dz1, loss_part);
+}
 
-    {   // de-phase co-resident workgroups (see mlp_forward_kernel)
-        const int slot = (blockIdx.x >> 8) % 3;
-        for (int i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-    TileRegs<MLP_H3> h3r;
-    tile_load<MLP_H3>(h3r, h3_saved, row0, n, tid);       // in flight during the loss phase
+// Forward and backward of one minibatch in ONE launch of 2 * tiles workgroups.  Both are row-local:
+// workgroup b < tiles runs the forward of tile b and publishes flag[b]; workgroup tiles + b waits
+// for that flag and runs the backward of tile b.  A launch of `tiles` workgroups at 3 per CU ends
+// in a ragged tail (5 tiles per CU at 40 960 rows: the last third of its time runs one or two
+// workgroups per CU); here the backward workgroups of the tiles that finished first fill the
+// slots the forward frees, so only ONE tail is left per minibatch instead of two.
+//  * No deadlock: workgroups are dispatched in blockIdx order, so every forward workgroup is
+//    resident or finished before its consumer starts to poll; a poll budget (~1 s) turns a lost
+//    flag into *err = 1 instead of a hang.
+//  * Visibility without cache maintenance: device-scope release/acquire fences would write back and
+//    invalidate the XCD's whole L2 per workgroup (measured: 1.6x slower, the weights keep getting
+//    evicted).  Instead producer and consumer are required to sit on the SAME XCD, i.e. behind
+//    the same L2: workgroups go round-robin over the 8 XCDs, and `tiles` is padded to a multiple
+//    of 8 by the launcher, so b and tiles + b land together.  The producer waits until its stores
+//    are acknowledged by L2 (vmcnt(0)) before it publishes the flag together with its XCC id; the
+//    consumer compares that id with its own and raises *err = 2 on a mismatch (the host then
+//    falls back to two launches).  The consumer's L1 cannot hold these lines: L1 is invalidated
+//    at kernel start and nothing on the CU has read this tile's rows since.
+constexpr int FB_LDS_FLOATS = FWD_LDS_FLOATS > BW_FLOATS ? FWD_LDS_FLOATS : BW_FLOATS;
 
-    // per-action constants of the diagonal Gaussian, once per workgroup: 1/L_j and sum log L_j
-    float* invL = red + 2;                                 // [18] (+1: half_log_det)
-    if (tid >= 64 && tid < 64 + MLP_NACT) invL[tid - 64] = 1.0f / sqrtf(var[tid - 64]);
-    if (tid == 96) {
-        float hl = 0.0f;
-        for (int j = 0; j < MLP_NACT; ++j) hl += logf(sqrtf(var[j]));
-        invL[MLP_NACT] = hl;
-    }
-    __syncthreads();
-    // per-row loss terms (one lane per row)
-    if (tid < BM) {
-        const long g = row0 + tid;
-        float c = 0.0f, pol = 0.0f, hub = 0.0f;
-        if (g < n) {
-            float M = 0.0f;
-            const float half_log_det = invL[MLP_NACT];
-#pragma unroll
-            for (int j = 0; j < MLP_NACT; ++j) {
-                const float xj = (action[g * MLP_NACT + j] - out_saved[g * MLP_OUT + j]) * invL[j];
-                M += xj * xj;
-            }
-            const float logp = -0.5f * (33.08178959434617f + M) - half_log_det;
-            const float ratio = expf(logp - old_logp[g]);
-            const float A = adv[g];
-            const float s1 = ratio * A;
-            const float rc = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
-            const float s2 = rc * A;
-            const float in_range = (ratio >= 1.0f - clip && ratio <= 1.0f + clip) ? 1.0f : 0.0f;
-            float dmin;                                    // d min(s1,s2) / d ratio
-            if (s1 < s2) dmin = A;
-            else if (s1 > s2) dmin = A * in_range;
-            else dmin = 0.5f * (A + A * in_range);
-            c = -inv_batch * ratio * dmin;                 // d loss / d logp
-            pol = -fminf(s1, s2);
-            const float d = out_saved[g * MLP_OUT + MLP_NACT] - target[g];
-            hub = fabsf(d) < 1.0f ? 0.5f * d * d : fabsf(d) - 0.5f;
-        }
-        coef[tid] = c;
-        for (int o = 16; o > 0; o >>= 1) { pol += __shfl_down(pol, o, 32); hub += __shfl_down(hub, o, 32); }
-        if (tid == 0) { red[0] = pol; red[1] = hub; }
-    }
-    tile_store_lds<MLP_H3>(h3r, ldsZ3, tid);
-    __syncthreads();
-    if (tid == 0 && loss_part) { loss_part[2 * blockIdx.x] = red[0]; loss_part[2 * blockIdx.x + 1] = red[1]; }
-    // dz4 tile
-    for (int i = tid; i < BM * MLP_OUT; i += THREADS) {
-        const int row = i / MLP_OUT, col = i - row * MLP_OUT;
-        const long g = row0 + row;
-        float d = 0.0f;
-        if (g < n) {
-            if (col < MLP_NACT) {
-                const float mu = out_saved[g * MLP_OUT + col];
-                d = coef[row] * (action[g * MLP_NACT + col] - mu) / var[col] * elu_grad_from_out(mu);
-            } else if (col == MLP_NACT) {
-                const float dv = out_saved[g * MLP_OUT + MLP_NACT] - target[g];
-                d = inv_batch * fminf(fmaxf(dv, -1.0f), 1.0f);           // smooth_l1', beta = 1
-            }
-            dz4[g * MLP_OUT + col] = d;
-        }
-        ldsZ4[row * (MLP_OUT + 4) + col] = d;
-    }
-    TileRegs<MLP_H2> h2r;
-    tile_load<MLP_H2>(h2r, h2_saved, row0, n, tid);
-    __syncthreads();
-    {   // dA3 = dZ4 . W4  ->  dZ3 (in place over the staged H3 tile)
-        f32x16 acc[1];
-        zero_acc(acc);
-        tile_gemm<MLP_OUT, 1>(PT + MLP_OFF_TF4, wave, ldsZ4, acc, lane);
-        epilogue_dact_inplace(acc[0], wave * 32, MLP_H3, ldsZ3, lane);
-    }
-    tile_store_lds<MLP_H2>(h2r, ldsZ2, tid);
-    __syncthreads();
-    copy_tile_out<MLP_H3>(ldsZ3, dz3, row0, n, tid);
-    {   // dA2 = dZ3 . W3  ->  dZ2
-        f32x16 acc[1];
-        zero_acc(acc);
-        tile_gemm<MLP_H3, 1>(PT + MLP_OFF_TF3, wave, ldsZ3, acc, lane);
-        epilogue_dact_inplace(acc[0], wave * 32, MLP_H2, ldsZ2, lane);
-    }
-    __syncthreads();                                       // Z3 / Z4 are dead from here: Z1 may overwrite them
-    copy_tile_out<MLP_H2>(ldsZ2, dz2, row0, n, tid);
-    {   // dA1 = dZ2 . W2  ->  dZ1
-        TileRegs<MLP_H1> h1r;
-        tile_load<MLP_H1>(h1r, h1_saved, row0, n, tid);    // in flight during the MFMAs
-        f32x16 acc[2];
-        zero_acc(acc);
-        tile_gemm<MLP_H2, 2>(PT + MLP_OFF_TF2, wave * 2, ldsZ2, acc, lane);
-        tile_store_lds<MLP_H1>(h1r, ldsZ1, tid);
+// s_memrealtime (100 MHz) with the CU identity in the top 16 bits (diagnostic stamps only)
+__device__ __forceinline__ unsigned long long realtime_cu()
+{
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+    return (t & 0xffffffffffffull) | ((unsigned long long)(((hw >> 8) & 0xff) | ((xcc & 0xf) << 8)) << 48);
+}
+
+template <bool STAMP>
+__global__ __launch_bounds__(THREADS, 3) void mlp_fwd_bwd_kernel(
+    const float* __restrict__ P, const float* __restrict__ PF, const float* __restrict__ PT,
+    const float* __restrict__ x, long n, float* __restrict__ out_save, float* __restrict__ h1_save,
+    float* __restrict__ h2_save, float* __restrict__ h3_save,
+    const float* __restrict__ action, const float* __restrict__ old_logp, const float* __restrict__ adv,
+    const float* __restrict__ target, const float* __restrict__ var, float inv_batch, float clip,
+    float* __restrict__ dz4, float* __restrict__ dz3, float* __restrict__ dz2, float* __restrict__ dz1,
+    float* __restrict__ loss_part, int* __restrict__ flags, int epoch, int* __restrict__ err,
+    unsigned long long* __restrict__ stamps)
+{
+    __shared__ __attribute__((aligned(16))) float lds[FB_LDS_FLOATS];
+    __shared__ int ok;
+    if (STAMP && threadIdx.x == 0) stamps[4L * blockIdx.x] = realtime_cu();
+    const long tiles = (n + BM - 1) / BM;
+    const long pad_tiles = (tiles + 7) & ~7L;              // consumers start at a multiple of 8: same XCD as their producer
+    if ((long)blockIdx.x < pad_tiles) {
+        const long tile = blockIdx.x;
+        if (tile >= tiles) return;
+        forward_body<false>(lds, tile, tiles, (blockIdx.x >> 8) % 3, P, PF, x, n, nullptr, nullptr, out_save, h1_save,
+                            h2_save, h3_save, nullptr, nullptr, nullptr, nullptr, nullptr);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);                    // this thread's stores have been acknowledged by L2
         __syncthreads();
-        epilogue_dact_inplace(acc[0], wave * 64, MLP_H1, ldsZ1, lane);
-        epilogue_dact_inplace(acc[1], wave * 64 + 32, MLP_H1, ldsZ1, lane);
+        if (threadIdx.x == 0) {
+            const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;
+            __hip_atomic_store(flags + tile, (epoch << 4) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (STAMP) stamps[4L * blockIdx.x + 1] = realtime_cu();
+        }
+    } else {
+        const long tile = (long)blockIdx.x - pad_tiles;
+        if (tile >= tiles) return;
+        if (threadIdx.x == 0) {
+            int state = 1;                                 // 0 ok, 1 flag never came, 2 producer on another XCD
+            for (int poll = 0; poll < (1 << 21); ++poll) {
+                const int f = __hip_atomic_load(flags + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((f >> 4) == epoch) {
+                    state = ((f & 0xf) == (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf)) ? 0 : 2;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(16);
+            }
+            ok = state;
+            if (state) atomicMax(err, state);
+        }
+        __syncthreads();
+        if (ok) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // ordering only: no cache maintenance (see above)
+        if (STAMP && threadIdx.x == 0) stamps[4L * blockIdx.x + 2] = realtime_cu();
+        backward_body(lds, tile, 0, PT, out_save, h1_save, h2_save, h3_save, action, old_logp, adv, target, var, n, inv_batch,
+                      clip, dz4, dz3, dz2, dz1, loss_part);
+        if (STAMP && threadIdx.x == 0) {
+            __builtin_amdgcn_s_waitcnt(0);
+            stamps[4L * blockIdx.x + 1] = realtime_cu();
+        }
     }
-    __syncthreads();
-    copy_tile_out<MLP_H1>(ldsZ1, dz1, row0, n, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -950,10 +1087,10 @@ extern "C" hipError_t flyhip_launch_mlp_forward_sample(const float* P, const flo
 // diagnostic build of the same kernel with phase stamps (tools/stamp_forward.py); not part of the ABI header
 extern "C" int flyhip_debug_mlp_forward_stamped(const float* P, const float* PF, const float* x, int64_t n,
                                                 float* out_save, float* h1_save, float* h2_save, float* h3_save,
-                                                unsigned long long* stamps, void* stream)
+                                                unsigned long long* stamps, void* stream, int grid_override)
 {
     const long tiles = (n + BM - 1) / BM;
-    const int grid = (int)(tiles <= 4 * 768 ? tiles : 768);
+    const int grid = grid_override > 0 ? grid_override : (int)(tiles <= 4 * 768 ? tiles : 768);
     hipLaunchKernelGGL(mlp_forward_kernel<true>, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PF, x, (long)n,
                        (float*)nullptr, (float*)nullptr, out_save, h1_save, h2_save, h3_save, (const float*)nullptr,
                        (const float*)nullptr, (float*)nullptr, (float*)nullptr, stamps);
@@ -976,6 +1113,37 @@ extern "C" hipError_t flyhip_launch_mlp_backward_dx(const float* PT, const float
 
 // workgroups per layer, proportional to the layer's share of the dW FLOPs (256 in total)
 static const int kGradWgs[4] = {72, 112, 56, 16};   // multiples of 8: every layer spreads evenly over the 8 XCDs
+
+extern "C" hipError_t flyhip_launch_mlp_fwd_bwd(const float* P, const float* PF, const float* PT, const float* x, int64_t n,
+                                                float* out_save, float* h1_save, float* h2_save, float* h3_save,
+                                                const float* action, const float* old_logp, const float* adv,
+                                                const float* target, const float* var, float inv_batch, float clip,
+                                                float* dz4, float* dz3, float* dz2, float* dz1, float* loss_part,
+                                                int* flags, int epoch, int* err, void* stream)
+{
+    const long tiles = (n + BM - 1) / BM;
+    const long pad_tiles = (tiles + 7) & ~7L;
+    hipLaunchKernelGGL(mlp_fwd_bwd_kernel<false>, dim3((unsigned)(pad_tiles + tiles)), dim3(THREADS), 0, (hipStream_t)stream, P,
+                       PF, PT, x, (long)n, out_save, h1_save, h2_save, h3_save, action, old_logp, adv, target, var, inv_batch,
+                       clip, dz4, dz3, dz2, dz1, loss_part, flags, epoch, err, (unsigned long long*)nullptr);
+    return hipGetLastError();
+}
+
+// diagnostic build with per-workgroup start/end stamps (tools/stamp_fwd_bwd.py); not part of the ABI header
+extern "C" int flyhip_debug_mlp_fwd_bwd_stamped(const float* P, const float* PF, const float* PT, const float* x, int64_t n,
+                                                float* out_save, float* h1_save, float* h2_save, float* h3_save,
+                                                const float* action, const float* old_logp, const float* adv,
+                                                const float* target, const float* var, float inv_batch, float clip,
+                                                float* dz4, float* dz3, float* dz2, float* dz1, float* loss_part,
+                                                int* flags, int epoch, int* err, unsigned long long* stamps, void* stream)
+{
+    const long tiles = (n + BM - 1) / BM;
+    const long pad_tiles = (tiles + 7) & ~7L;
+    hipLaunchKernelGGL(mlp_fwd_bwd_kernel<true>, dim3((unsigned)(pad_tiles + tiles)), dim3(THREADS), 0, (hipStream_t)stream, P,
+                       PF, PT, x, (long)n, out_save, h1_save, h2_save, h3_save, action, old_logp, adv, target, var, inv_batch,
+                       clip, dz4, dz3, dz2, dz1, loss_part, flags, epoch, err, stamps);
+    return (int)hipGetLastError();
+}
 
 extern "C" int64_t flyhip_mlp_grad_workspace_floats(void)
 {

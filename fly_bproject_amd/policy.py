@@ -6,6 +6,7 @@ optimizers) and the HIP kernels see the same memory.  Padding and the structural
 stacked last layer never receive gradient (`grad_mask`).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -153,6 +154,12 @@ class PackedPolicy:
         self.dz = {"dz4": torch.empty(r, OUT, device=dev), "dz3": torch.empty(r, H3, device=dev),
                    "dz2": torch.empty(r, H2, device=dev), "dz1": torch.empty(r, H1, device=dev)}
         self.loss_part = torch.zeros((r + 31) // 32, 2, device=dev)
+        # mlp_forward_backward: per-tile "forward done" words (compared against a per-call epoch,
+        # never reset) and the word a workgroup sets if it ever gives up waiting (stays 0)
+        self._tile_flags = torch.zeros((r + 31) // 32, dtype=torch.int32, device=dev)
+        self.tile_wait_error = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._epoch = 0
+        self.fuse_fwd_bwd = os.environ.get("FLY_FUSE_FWD_BWD", "1") != "0"
 
     def minibatch_grad(self, x, action, old_logp, adv, target, var, clip, global_rows=None, fuse_norm=False):
         """Forward + loss + backward of one minibatch; leaves the packed gradient in `self.G`.
@@ -165,13 +172,25 @@ class PackedPolicy:
         s, d = self.saves, self.dz
         p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
         st = _lib.stream_ptr()
-        _lib.check(self._lib.mlp_forward(p(self.P), p(self.PF), p(x), C.c_int64(n), None, None, p(s["out"]), p(s["h1"]),
-                                         p(s["h2"]), p(s["h3"]), st), "mlp_forward")
         inv_b = 1.0 / float(global_rows if global_rows else n)
-        _lib.check(self._lib.mlp_backward_dx(p(self.PT), p(s["out"]), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(action),
-                                             p(old_logp), p(adv), p(target), p(var), C.c_int64(n), C.c_float(inv_b),
-                                             C.c_float(clip), p(d["dz4"]), p(d["dz3"]), p(d["dz2"]), p(d["dz1"]),
-                                             p(self.loss_part), st), "mlp_backward_dx")
+        if self.fuse_fwd_bwd:
+            # one launch: the backward workgroup of a row tile starts when that tile's forward is done
+            if self._epoch >= (1 << 27) - 1:
+                self._tile_flags.zero_()
+                self._epoch = 0
+            self._epoch += 1
+            _lib.check(self._lib.mlp_forward_backward(
+                p(self.P), p(self.PF), p(self.PT), p(x), C.c_int64(n), p(s["out"]), p(s["h1"]), p(s["h2"]), p(s["h3"]),
+                p(action), p(old_logp), p(adv), p(target), p(var), C.c_float(inv_b), C.c_float(clip),
+                p(d["dz4"]), p(d["dz3"]), p(d["dz2"]), p(d["dz1"]), p(self.loss_part), p(self._tile_flags),
+                C.c_int(self._epoch), p(self.tile_wait_error), st), "mlp_forward_backward")
+        else:
+            _lib.check(self._lib.mlp_forward(p(self.P), p(self.PF), p(x), C.c_int64(n), None, None, p(s["out"]), p(s["h1"]),
+                                             p(s["h2"]), p(s["h3"]), st), "mlp_forward")
+            _lib.check(self._lib.mlp_backward_dx(p(self.PT), p(s["out"]), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(action),
+                                                 p(old_logp), p(adv), p(target), p(var), C.c_int64(n), C.c_float(inv_b),
+                                                 C.c_float(clip), p(d["dz4"]), p(d["dz3"]), p(d["dz2"]), p(d["dz1"]),
+                                                 p(self.loss_part), st), "mlp_backward_dx")
         nm = (p(self.grad_mask), p(self._norm_ws), p(self.step)) if fuse_norm else (None, None, None)
         _lib.check(self._lib.mlp_grad_w(p(x), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(d["dz1"]), p(d["dz2"]),
                                         p(d["dz3"]), p(d["dz4"]), C.c_int64(n), p(self.workspace), p(self.G), *nm, st),

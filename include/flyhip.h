@@ -240,6 +240,23 @@ int mlp_backward_dx(const float* params_t_frag, const float* out_saved, const fl
                     const float* old_logp, const float* adv, const float* target, const float* var,
                     int64_t n, float inv_batch, float clip, float* dz4, float* dz3, float* dz2,
                     float* dz1, float* loss_part, void* stream);
+
+/* mlp_forward (activations saved) and mlp_backward_dx of the same n rows in ONE launch: both are
+ * row-local, so the backward workgroup of a 32-row tile starts as soon as that tile's forward has
+ * published its flag, and fills the slots the forward launch's ragged tail would leave idle.
+ * Results are bit-identical to the two separate calls.  `flags` int32 [ceil(n/32)] device scratch
+ * (zero-initialised; re-zero it before `epoch` wraps), `epoch` in [1, 2^27) a value that differs
+ * from every earlier call on these flags (a counter), `err` int32 [1] device word, normally 0:
+ * 1 = a workgroup gave up waiting for its tile (the wait is bounded, a lost flag cannot hang the
+ * device), 2 = a tile's forward and backward workgroups were not placed on the same XCD, which the
+ * kernel relies on instead of L2 write-back/invalidate per workgroup.  Non-zero => results of
+ * that call are invalid; use mlp_forward + mlp_backward_dx instead. */
+int mlp_forward_backward(const float* params, const float* params_frag, const float* params_t_frag,
+                         const float* x, int64_t n, float* out_save, float* h1_save, float* h2_save,
+                         float* h3_save, const float* action, const float* old_logp, const float* adv,
+                         const float* target, const float* var, float inv_batch, float clip,
+                         float* dz4, float* dz3, float* dz2, float* dz1, float* loss_part,
+                         int32_t* flags, int32_t epoch, int32_t* err, void* stream);
 int mlp_grad_w(const float* x, const float* h1_saved, const float* h2_saved, const float* h3_saved,
                const float* dz1, const float* dz2, const float* dz3, const float* dz4, int64_t n,
                float* workspace, float* grad, const float* norm_mask, float* norm_ws, int32_t* norm_step,

@@ -176,3 +176,28 @@ def test_fused_norm_step_matches_two_launch_step():
     np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-5)
     torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(outs[0][3], outs[1][3], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("n", [16, 4099, 40960])
+def test_one_launch_forward_backward_equals_two_launches(n):
+    """mlp_forward_backward (backward workgroups wait on per-tile flags of the forward workgroups of
+    the same launch) leaves bit for bit what mlp_forward followed by mlp_backward_dx leave, call
+    after call on the same flag words, and never reports a lost flag."""
+    net, ref, pol, (x, action, old_logp, adv, target, var) = _setup(n, 11)
+    res = {}
+    for fuse in (False, True, True):
+        pol.fuse_fwd_bwd = fuse
+        for t in list(pol.saves.values()) + list(pol.dz.values()) + [pol.loss_part, pol.G]:
+            t.fill_(float("nan"))
+        pol.minibatch_grad(x, action, old_logp, adv, target, var, 0.2)
+        torch.cuda.synchronize()
+        got = [pol.saves[k][:n].clone() for k in ("out", "h1", "h2", "h3")] + \
+              [pol.dz[k][:n].clone() for k in ("dz4", "dz3", "dz2", "dz1")] + \
+              [pol.loss_part[: (n + 31) // 32].clone(), pol.G.clone()]
+        assert all(torch.isfinite(t).all() for t in got)
+        if fuse:
+            for a, b in zip(res[False], got):
+                assert torch.equal(a, b)
+        else:
+            res[False] = got
+    assert int(pol.tile_wait_error.item()) == 0 and pol._epoch == 2

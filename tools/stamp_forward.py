@@ -24,9 +24,10 @@ stamps = torch.zeros(grid * 16, dtype=torch.int64, device="cuda:0")
 p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
 s = pol.saves
 fn = lib.flyhip_debug_mlp_forward_stamped
-fn.argtypes = [C.c_void_p] * 3 + [C.c_int64] + [C.c_void_p] * 6
+fn.argtypes = [C.c_void_p] * 3 + [C.c_int64] + [C.c_void_p] * 6 + [C.c_int]
+GRID = int(os.environ.get("GRID", "0"))        # > 0: persistent workgroups walking tiles b, b+GRID, ...
 for _ in range(3):
-    fn(p(pol.P), p(pol.PF), p(x), rows, p(s["out"]), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(stamps), None)
+    fn(p(pol.P), p(pol.PF), p(x), rows, p(s["out"]), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(stamps), None, GRID)
 torch.cuda.synchronize()
 raw = stamps.cpu().numpy().reshape(grid, 16).astype(np.int64)
 raw = raw[raw[:, 13] > 0]                      # workgroups that stamped (persistent grids are smaller)
