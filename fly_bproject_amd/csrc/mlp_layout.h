@@ -24,7 +24,10 @@
 // Fragment order of a [N][K] operand (N outputs, K reduced): element (n, k) lives at
 //     (((n/32) * (K/8) + kq) * 64 + (h*32 + n%32)) * 4 + q,   h = k / (K/2), kk = k % (K/2),
 //     kq = kk / 4, q = kk % 4
-// i.e. [column tile][k-quad][lane][4].  Layer 4 forward (split-K over the four waves) uses
+// i.e. [column tile][k-quad][lane][4].  Layer 2 forward is stored as TWO such operands with K = 128
+// (k in [0,128) at MLP_OFF_F2, k in [128,256) at MLP_OFF_F2 + 128*128): the forward kernel keeps only
+// one 128-column half of H1 in LDS at a time and accumulates layer 2 over the two k ranges.
+// Layer 4 forward (split-K over the four waves) uses
 //     ((w*4 + kq) * 64 + (h*32 + n)) * 4 + q,   w = k/32, h = (k%32)/16, kq = (k%16)/4, q = k%4.
 // fly_bproject_amd/policy.py builds the index maps; mlp_adam_step scatters every updated weight
 // into PF/PTF, so the three buffers never diverge.

@@ -46,90 +46,86 @@ __device__ __forceinline__ float elu_grad_from_out(float y) { return y > 0.0f ? 
 //   Wf     : this layer's weights in fragment order (mlp_layout.h): [col tile][K/8][64 lanes][4];
 //            `tile0` = first column tile of this wave.  One wave-instruction = one contiguous KiB.
 // k mapping: MFMA step s = 4*kq+q multiplies k = 4*kq+q (lanes 0..31) and k = K/2+4*kq+q (32..63).
-// The first two weight k-quads of a GEMM, requested AHEAD of it: a caller issues `gemm_prefetch`
-// before the previous layer's epilogue / barrier / copy-out so the L2 round trip (1-2 k cycles,
-// once per layer per tile) hides under that work instead of opening every MFMA loop.
+// Measured on MI355X (tools/mfma_valu_overlap.hip): VALU, LDS and VMEM instructions do NOT execute under
+// a running MFMA of the same SIMD -- every v_mov / address add / s_waitcnt stall in a GEMM loop is
+// matrix-pipe time lost.  So the k loop is straight-line code: fully unrolled over a ring of four
+// NAMED operand sets (compile-time indices -> registers, no copies), each set reloaded right
+// after the four MFMAs that consumed it, i.e. three sets (768 matrix cycles) ahead of its next
+// use; sched_barriers pin that order so the scheduler can neither hoist the loads (register
+// blow-up) nor sink them (exposed L2 latency).  The first MFMA of an accumulator takes the
+// constant 0 as its C operand, so no accumulator clearing is issued either.
+//
+// The first two weight k-quads of a GEMM are requested AHEAD of it: a caller issues `gemm_prefetch`
+// before the previous layer's epilogue / barrier so the L2 round trip (1-2 k cycles, once per layer
+// per tile) hides under that work instead of opening every MFMA run.
+constexpr int RING = 4, HEAD = 2, ARING = 2;      // weight sets (L2 latency), head sets, activation sets (LDS latency)
 template <int NT>
-struct WeightHead { float4 b0[NT], b1[NT]; };
+struct WeightHead { float4 b[HEAD][NT]; };
 
 template <int K, int NT>
 __device__ __forceinline__ void gemm_prefetch(WeightHead<NT>& w, const float* __restrict__ Wf, int tile0, int lane)
 {
+    static_assert(K / 8 >= RING, "at least RING k-quads");
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const float* bp = Wf + (long)(tile0 + t) * (K / 8) * 256 + lane * 4;
-        w.b0[t] = *reinterpret_cast<const float4*>(bp);
-        w.b1[t] = *reinterpret_cast<const float4*>(bp + 256);
+#pragma unroll
+        for (int s = 0; s < HEAD; ++s) w.b[s][t] = *reinterpret_cast<const float4*>(bp + 256 * s);
     }
 }
 
-template <int K, int NT>
+// ZERO: the accumulators start from 0 (their incoming value is ignored); otherwise they are added to.
+template <int K, int NT, bool ZERO = true>
 __device__ __forceinline__ void tile_gemm(const WeightHead<NT>& head, const float* __restrict__ Wf, int tile0,
                                           const float* lds_in, f32x16 (&acc)[NT], int lane)
 {
+    constexpr int K8 = K / 8;
     const int r = lane & 31, h = lane >> 5;
     const float* ap = lds_in + r * (K + 4) + h * (K / 2);
     const float* bp[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) bp[t] = Wf + (long)(tile0 + t) * (K / 8) * 256 + lane * 4;
-    // B fragments (L2) are requested two k-quads ahead, A fragments (LDS) one k-quad ahead of the
-    // MFMAs that consume them.  The two-deep ring is two NAMED register sets walked in pairs (a
-    // runtime-indexed ring would live in scratch).
-    static_assert((K / 8) % 2 == 0, "k-quads are walked in pairs");
-    float4 b0[NT], b1[NT];
+    for (int t = 0; t < NT; ++t) bp[t] = Wf + (long)(tile0 + t) * K8 * 256 + lane * 4;
+    float4 b[RING][NT], a[ARING];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        b0[t] = head.b0[t];
-        b1[t] = head.b1[t];
+    for (int s = 0; s < RING; ++s) {
+        if (s < ARING) a[s] = *reinterpret_cast<const float4*>(ap + 4 * s);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            b[s][t] = s < HEAD ? head.b[s][t] : *reinterpret_cast<const float4*>(bp[t] + 256 * s);
     }
-    float4 a0 = *reinterpret_cast<const float4*>(ap);
-#pragma unroll 1
-    for (int kq = 0; kq < K / 8; kq += 2) {
-        // ---- k-quad kq: consume (a0, b0); request A of kq+1 and B of kq+2
-        float4 a1 = *reinterpret_cast<const float4*>(ap + 4 * (kq + 1));
-        float4 bu[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) bu[t] = b0[t];
-        if (kq + 2 < K / 8) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) b0[t] = *reinterpret_cast<const float4*>(bp[t] + 256 * (kq + 2));
-        }
+    for (int kq = 0; kq < K8; ++kq) {
+        const int s = kq % RING, sa = kq % ARING;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bu[t].x, a0.x, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bu[t].y, a0.y, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bu[t].z, a0.z, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bu[t].w, a0.w, acc[t], 0, 0, 0);
+            if (ZERO && kq == 0) {
+                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s][t].x, a[sa].x, z, 0, 0, 0);
+            } else {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s][t].x, a[sa].x, acc[t], 0, 0, 0);
+            }
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s][t].y, a[sa].y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s][t].z, a[sa].z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s][t].w, a[sa].w, acc[t], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        // ---- k-quad kq+1: consume (a1, b1); request A of kq+2 and B of kq+3
-        if (kq + 2 < K / 8) a0 = *reinterpret_cast<const float4*>(ap + 4 * (kq + 2));
+        if (kq + RING < K8) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) bu[t] = b1[t];
-        if (kq + 3 < K / 8) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) b1[t] = *reinterpret_cast<const float4*>(bp[t] + 256 * (kq + 3));
+            for (int t = 0; t < NT; ++t) b[s][t] = *reinterpret_cast<const float4*>(bp[t] + 256 * (kq + RING));
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bu[t].x, a1.x, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bu[t].y, a1.y, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bu[t].z, a1.z, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bu[t].w, a1.w, acc[t], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        if (kq + ARING < K8) a[sa] = *reinterpret_cast<const float4*>(ap + 4 * (kq + ARING));
     }
+    __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int K, int NT>
+template <int K, int NT, bool ZERO = true>
 __device__ __forceinline__ void tile_gemm(const float* __restrict__ Wf, int tile0, const float* lds_in,
                                           f32x16 (&acc)[NT], int lane)
 {
     WeightHead<NT> head;
     gemm_prefetch<K, NT>(head, Wf, tile0, lane);
-    tile_gemm<K, NT>(head, Wf, tile0, lds_in, acc, lane);
+    tile_gemm<K, NT, ZERO>(head, Wf, tile0, lds_in, acc, lane);
 }
 
 // C/D layout of the 32x32 tile with the operand roles above: lane holds row (lane&31) and output
@@ -142,13 +138,14 @@ __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8
 // store, and -- when `gdst` is given -- the same 16 bytes to the saved-activation rows in HBM.  A
 // wave's four stores of one column tile touch the same 32 lines (one 128-byte line per row) and
 // together fill them, so L2 merges them into full-line writes; no LDS read-back pass is needed.
-template <int N, int NT>
+template <int N, int NT, int NG = N>
 __device__ __forceinline__ void epilogue_elu(const f32x16 (&acc)[NT], const float* __restrict__ bias, int col0,
-                                             float* lds_out, int lane, float* __restrict__ gdst, long row0, long nrows)
+                                             float* lds_out, int lane, float* __restrict__ gdst, long row0, long nrows,
+                                             int gcol0 = 0)
 {
     const int r = lane & 31;
     const bool st = gdst != nullptr && row0 + r < nrows;
-    float* grow = gdst + (row0 + r) * N;
+    float* grow = gdst + (row0 + r) * NG + gcol0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -175,7 +172,13 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NT])
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
 }
 
-constexpr int LDS_A_FLOATS = BM * (MLP_H1 + 4);      // H1, later H3
+// Both tile kernels fit four workgroups per CU: <= 40 KB of LDS and <= 128 VGPRs each.
+constexpr int WGS_PER_CU = 4;
+constexpr int PERSIST_GRID = 256 * WGS_PER_CU;       // persistent launches: every slot of the chip
+#ifndef DEPHASE_SLEEP
+#define DEPHASE_SLEEP 95
+#endif
+constexpr int LDS_A_FLOATS = BM * (MLP_H2 + 4);      // one 128-column half of H1 at a time, later H3
 constexpr int LDS_B_FLOATS = BM * (MLP_H2 + 4);      // X0, later H2, later the split-K partials
 constexpr int LB1 = 0, LB2 = MLP_H1, LB3 = LB2 + MLP_H2, LB4 = LB3 + MLP_H3, LSD = LB4 + MLP_OUT, LLG = LSD + 32;
 constexpr int LDS_C_FLOATS = LLG + 32;               // biases + sampling constants (2.4 KB)
@@ -220,7 +223,7 @@ __device__ __forceinline__ void forward_body(
     float* ldsA = lds;
     float* ldsB = lds + LDS_A_FLOATS;
     float* ldsBias = ldsB + LDS_B_FLOATS;   // b1 | b2 | b3 | b4 | sqrt(var) | log sqrt(var): read by every epilogue
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR: weight bases become scalar
     const long ntiles = (n + BM - 1) / BM;
     const long total = n * MLP_IN;
 
@@ -267,7 +270,7 @@ __device__ __forceinline__ void forward_body(
     // epilogues together (matrix pipe idle).  Workgroups b, b+256, b+512 are the ones the dispatcher
     // co-locates first; delaying the second and third by one and two thirds of a tile's solo time
     // lets one group's epilogue hide under the others' MFMAs.  Speed only, never correctness.
-    for (int i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(127);     // 127 * 64 cycles each
+    for (int i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(DEPHASE_SLEEP);     // x 64 cycles each
     long tile = first_tile;
     if (tile < ntiles) x_load(tile);
     {   // biases (and the sampling constants) -> LDS once per workgroup; the first tile's barrier publishes them
@@ -297,40 +300,49 @@ __device__ __forceinline__ void forward_body(
             t = (t & 0xffffffffffffull) | ((unsigned long long)(((hw >> 8) & 0xff) | ((xcc & 0xf) << 8)) << 48);
             stamps[14] = t;
         }
-        WeightHead<2> w1;
-        gemm_prefetch<MLP_IN_PAD, 2>(w1, PF + MLP_OFF_F1, wave * 2, lane);    // lands during the x staging
+        // Layers 1 and 2 run in two halves of 128 hidden-1 columns so that only a [32][132] slice of
+        // H1 is ever in LDS (36 KB per workgroup -> four workgroups per CU): L1 produces columns
+        // [0,128), L2 accumulates their k range, L1 produces [128,256), L2 accumulates the rest.
+        WeightHead<1> w1a, w1b, w2a, w2b, w3;
+        gemm_prefetch<MLP_IN_PAD, 1>(w1a, PF + MLP_OFF_F1, wave, lane);       // lands during the x staging
         x_store(tl);
         __syncthreads();
         if (tile + tile_stride < ntiles) x_load(tile + tile_stride);     // lands during this tile's MFMAs
         stamp<STAMP>(stamps, 1);
-        WeightHead<1> w2, w3;
-        {   // L1: 80 -> 256, wave owns 64 columns
-            f32x16 acc[2];
-            zero_acc(acc);
-            tile_gemm<MLP_IN_PAD, 2>(w1, PF + MLP_OFF_F1, wave * 2, ldsB, acc, lane);
+        f32x16 acc2[1];
+        {   // L1, columns [0,128): wave owns 32 of them
+            f32x16 acc[1];
+            tile_gemm<MLP_IN_PAD, 1>(w1a, PF + MLP_OFF_F1, wave, ldsB, acc, lane);
             stamp<STAMP>(stamps, 2);
-            gemm_prefetch<MLP_H1, 1>(w2, PF + MLP_OFF_F2, wave, lane);        // lands during epilogue + copy-out
-            epilogue_elu<MLP_H1, 2>(acc, ldsBias + LB1, wave * 64, ldsA, lane, h1_save, row0, n);
+            gemm_prefetch<MLP_H2, 1>(w2a, PF + MLP_OFF_F2, wave, lane);           // both land during the epilogue
+            gemm_prefetch<MLP_IN_PAD, 1>(w1b, PF + MLP_OFF_F1, 4 + wave, lane);
+            epilogue_elu<MLP_H2, 1, MLP_H1>(acc, ldsBias + LB1, wave * 32, ldsA, lane, h1_save, row0, n);
         }
         stamp<STAMP>(stamps, 3);
         __syncthreads();
         stamp<STAMP>(stamps, 4);
-        stamp<STAMP>(stamps, 5);
-        {   // L2: 256 -> 128, wave owns 32 columns
+        {   // L2 over k in [0,128), then L1 columns [128,256) -- one uninterrupted run of MFMAs
             f32x16 acc[1];
-            zero_acc(acc);
-            tile_gemm<MLP_H1, 1>(w2, PF + MLP_OFF_F2, wave, ldsA, acc, lane);
-            stamp<STAMP>(stamps, 6);
-            gemm_prefetch<MLP_H2, 1>(w3, PF + MLP_OFF_F3, wave, lane);
-            epilogue_elu<MLP_H2, 1>(acc, ldsBias + LB2, wave * 32, ldsB, lane, h2_save, row0, n);
+            tile_gemm<MLP_H2, 1>(w2a, PF + MLP_OFF_F2, wave, ldsA, acc2, lane);
+            tile_gemm<MLP_IN_PAD, 1>(w1b, PF + MLP_OFF_F1, 4 + wave, ldsB, acc, lane);
+            stamp<STAMP>(stamps, 5);
+            gemm_prefetch<MLP_H2, 1>(w2b, PF + MLP_OFF_F2 + MLP_H2 * (MLP_H1 / 2), wave, lane);
+            __syncthreads();                                   // every wave has finished reading the first half of H1
+            epilogue_elu<MLP_H2, 1, MLP_H1>(acc, ldsBias + LB1 + MLP_H1 / 2, wave * 32, ldsA, lane, h1_save, row0, n, MLP_H1 / 2);
         }
-        stamp<STAMP>(stamps, 7);
+        stamp<STAMP>(stamps, 6);
         __syncthreads();
-        stamp<STAMP>(stamps, 8);
+        stamp<STAMP>(stamps, 7);
+        {   // L2 over k in [128,256): 256 -> 128 complete, wave owns 32 columns
+            tile_gemm<MLP_H2, 1, false>(w2b, PF + MLP_OFF_F2 + MLP_H2 * (MLP_H1 / 2), wave, ldsA, acc2, lane);
+            stamp<STAMP>(stamps, 8);
+            gemm_prefetch<MLP_H2, 1>(w3, PF + MLP_OFF_F3, wave, lane);
+            epilogue_elu<MLP_H2, 1>(acc2, ldsBias + LB2, wave * 32, ldsB, lane, h2_save, row0, n);   // x is dead: every wave passed the barrier above
+        }
+        __syncthreads();
         float4 w4[4];                                                            // layer-4 weights of this wave's k range
         {   // L3: 128 -> 128 (actor | critic heads stacked)
             f32x16 acc[1];
-            zero_acc(acc);
             stamp<STAMP>(stamps, 9);
             tile_gemm<MLP_H2, 1>(w3, PF + MLP_OFF_F3, wave, ldsB, acc, lane);
             stamp<STAMP>(stamps, 10);
@@ -405,7 +417,7 @@ __device__ __forceinline__ void forward_body(
 }
 
 template <bool STAMP>
-__global__ __launch_bounds__(THREADS, 3) void mlp_forward_kernel(
+__global__ __launch_bounds__(THREADS, 2) void mlp_forward_kernel(
     const float* __restrict__ P, const float* __restrict__ PF, const float* __restrict__ x, long n,
     float* __restrict__ mu_out, float* __restrict__ v_out, float* __restrict__ out_save,
     float* __restrict__ h1_save, float* __restrict__ h2_save, float* __restrict__ h3_save,
@@ -413,7 +425,7 @@ __global__ __launch_bounds__(THREADS, 3) void mlp_forward_kernel(
     float* __restrict__ smp_logp, unsigned long long* __restrict__ stamps_base)
 {
     __shared__ __attribute__((aligned(16))) float lds[FWD_LDS_FLOATS];
-    forward_body<STAMP>(lds, blockIdx.x, gridDim.x, (blockIdx.x >> 8) % 3, P, PF, x, n, mu_out, v_out, out_save, h1_save,
+    forward_body<STAMP>(lds, blockIdx.x, gridDim.x, (blockIdx.x >> 8) % WGS_PER_CU, P, PF, x, n, mu_out, v_out, out_save, h1_save,
                         h2_save, h3_save, smp_eps, smp_var, smp_act, smp_logp, stamps_base);
 }
 
@@ -478,7 +490,6 @@ constexpr int BW_Z3 = BW_Z2 + BM * (MLP_H2 + 4);           // [32][132]
 constexpr int BW_Z4 = BW_Z3 + BM * (MLP_H3 + 4);           // [32][36]
 constexpr int BW_TAIL = BW_Z4 + BM * (MLP_OUT + 4);        // [32][2] per-row loss terms
 constexpr int BW_FLOATS = BW_TAIL + 2 * BM;                // 38.9 KB
-constexpr int BW_WGS_PER_CU = 3;
 
 __device__ __forceinline__ void backward_body(
     float* lds, const long tile, const int slot,
@@ -493,11 +504,11 @@ __device__ __forceinline__ void backward_body(
     float* ldsZ3 = lds + BW_Z3;
     float* ldsZ4 = lds + BW_Z4;
     float* rowloss = lds + BW_TAIL;                        // [32][2]: policy term, Huber term of each row
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR: weight bases become scalar
     const long row0 = tile * BM;
 
     // de-phase co-resident workgroups (see forward_body)
-    for (int i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(127);
+    for (int i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(DEPHASE_SLEEP);
     WeightHead<1> wt4, wt3;
     gemm_prefetch<MLP_OUT, 1>(wt4, PT + MLP_OFF_TF4, wave, lane);
     HFrag<1> hf3;
@@ -559,7 +570,6 @@ __device__ __forceinline__ void backward_body(
     HFrag<1> hf2;
     {   // dA3 = dZ4 . W4  ->  dZ3
         f32x16 acc[1];
-        zero_acc(acc);
         tile_gemm<MLP_OUT, 1>(wt4, PT + MLP_OFF_TF4, wave, ldsZ4, acc, lane);
         gemm_prefetch<MLP_H3, 1>(wt3, PT + MLP_OFF_TF3, wave, lane);          // both land during the epilogue + barrier
         hfrag_load<MLP_H2, 1>(hf2, h2_saved, row0, n, wave * 32, lane);
@@ -570,7 +580,6 @@ __device__ __forceinline__ void backward_body(
     HFrag<2> hf1;
     {   // dA2 = dZ3 . W3  ->  dZ2
         f32x16 acc[1];
-        zero_acc(acc);
         tile_gemm<MLP_H3, 1>(wt3, PT + MLP_OFF_TF3, wave, ldsZ3, acc, lane);
         gemm_prefetch<MLP_H2, 2>(wt2, PT + MLP_OFF_TF2, wave * 2, lane);
         epilogue_dact<MLP_H2, 1>(acc, hf2, wave * 32, ldsZ2, dz2, row0, n, lane);
@@ -579,13 +588,12 @@ __device__ __forceinline__ void backward_body(
     {   // dA1 = dZ2 . W2  ->  dZ1 (no later GEMM reads it: HBM only)
         hfrag_load<MLP_H1, 2>(hf1, h1_saved, row0, n, wave * 64, lane);       // lands during the MFMAs
         f32x16 acc[2];
-        zero_acc(acc);
         tile_gemm<MLP_H2, 2>(wt2, PT + MLP_OFF_TF2, wave * 2, ldsZ2, acc, lane);
         epilogue_dact<MLP_H1, 2>(acc, hf1, wave * 64, nullptr, dz1, row0, n, lane);
     }
 }
 
-__global__ __launch_bounds__(THREADS, BW_WGS_PER_CU) void mlp_backward_dx_kernel(
+__global__ __launch_bounds__(THREADS, WGS_PER_CU) void mlp_backward_dx_kernel(
     const float* __restrict__ PT, const float* __restrict__ out_saved, const float* __restrict__ h1_saved,
     const float* __restrict__ h2_saved, const float* __restrict__ h3_saved,
     const float* __restrict__ action, const float* __restrict__ old_logp, const float* __restrict__ adv,
@@ -594,7 +602,7 @@ __global__ __launch_bounds__(THREADS, BW_WGS_PER_CU) void mlp_backward_dx_kernel
     float* __restrict__ loss_part)
 {
     __shared__ __attribute__((aligned(16))) float lds[BW_FLOATS];
-    backward_body(lds, blockIdx.x, (blockIdx.x >> 8) % BW_WGS_PER_CU, PT, out_saved, h1_saved, h2_saved, h3_saved, action,
+    backward_body(lds, blockIdx.x, (blockIdx.x >> 8) % WGS_PER_CU, PT, out_saved, h1_saved, h2_saved, h3_saved, action,
                   old_logp, adv, target, var, n, inv_batch, clip, dz4, dz3, dz2, dz1, loss_part);
 }
 
@@ -628,7 +636,7 @@ __device__ __forceinline__ unsigned long long realtime_cu()
 }
 
 template <bool STAMP>
-__global__ __launch_bounds__(THREADS, 3) void mlp_fwd_bwd_kernel(
+__global__ __launch_bounds__(THREADS, WGS_PER_CU) void mlp_fwd_bwd_kernel(
     const float* __restrict__ P, const float* __restrict__ PF, const float* __restrict__ PT,
     const float* __restrict__ x, long n, float* __restrict__ out_save, float* __restrict__ h1_save,
     float* __restrict__ h2_save, float* __restrict__ h3_save,
@@ -646,7 +654,7 @@ __global__ __launch_bounds__(THREADS, 3) void mlp_fwd_bwd_kernel(
     if ((long)blockIdx.x < pad_tiles) {
         const long tile = blockIdx.x;
         if (tile >= tiles) return;
-        forward_body<false>(lds, tile, tiles, (blockIdx.x >> 8) % 3, P, PF, x, n, nullptr, nullptr, out_save, h1_save,
+        forward_body<false>(lds, tile, tiles, (blockIdx.x >> 8) % WGS_PER_CU, P, PF, x, n, nullptr, nullptr, out_save, h1_save,
                             h2_save, h3_save, nullptr, nullptr, nullptr, nullptr, nullptr);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);                    // this thread's stores have been acknowledged by L2
@@ -718,7 +726,7 @@ __device__ void grad_w_layer(const GradWLayer& L, long nrows, int wg, float* lds
     constexpr int AV = A_VEC ? (GW_ROWS * KA / 4 + GW_THREADS - 1) / GW_THREADS
                              : (GW_ROWS * KA + GW_THREADS - 1) / GW_THREADS;     // float4 or float per thread
     constexpr int BUF = GW_ROWS * (N + KPAD);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR: weight bases become scalar
     const int r = lane & 31, h = lane >> 5;
     const bool active = wave < WN * WK;
     const int wn = active ? wave / WK : 0, wk = active ? wave % WK : 0;
@@ -1063,9 +1071,9 @@ extern "C" hipError_t flyhip_launch_mlp_forward(const float* P, const float* PF,
     // Large inputs (the critic pass over the whole rollout) run persistent workgroups, 3 per CU, each
     // walking many tiles with the next tile's rows prefetched.  Up to a few tiles per slot the
     // hardware's dynamic workgroup dispatch balances better than a fixed walk (1280 tiles over 768
-    // slots would leave a third of the chip idle for the second half), so those launch one tile each.
+    // slots would leave part of the chip idle for the second half), so those launch one tile each.
     const long tiles = (n + BM - 1) / BM;
-    const int grid = (int)(tiles <= 4 * 768 ? tiles : 768);
+    const int grid = (int)(tiles <= 4 * PERSIST_GRID ? tiles : PERSIST_GRID);
     hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PF, x, (long)n,
                        mu_out, v_out, out_save, h1_save, h2_save, h3_save, (const float*)nullptr, (const float*)nullptr,
                        (float*)nullptr, (float*)nullptr, (unsigned long long*)nullptr);
@@ -1077,7 +1085,7 @@ extern "C" hipError_t flyhip_launch_mlp_forward_sample(const float* P, const flo
                                                        float* logp_out, float* mu_out, float* v_out, void* stream)
 {
     const long tiles = (n + BM - 1) / BM;
-    const int grid = (int)(tiles <= 4 * 768 ? tiles : 768);
+    const int grid = (int)(tiles <= 4 * PERSIST_GRID ? tiles : PERSIST_GRID);
     hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PF, x, (long)n,
                        mu_out, v_out, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, eps,
                        var, act_out, logp_out, (unsigned long long*)nullptr);
@@ -1090,7 +1098,7 @@ extern "C" int flyhip_debug_mlp_forward_stamped(const float* P, const float* PF,
                                                 unsigned long long* stamps, void* stream, int grid_override)
 {
     const long tiles = (n + BM - 1) / BM;
-    const int grid = grid_override > 0 ? grid_override : (int)(tiles <= 4 * 768 ? tiles : 768);
+    const int grid = grid_override > 0 ? grid_override : (int)(tiles <= 4 * PERSIST_GRID ? tiles : PERSIST_GRID);
     hipLaunchKernelGGL(mlp_forward_kernel<true>, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PF, x, (long)n,
                        (float*)nullptr, (float*)nullptr, out_save, h1_save, h2_save, h3_save, (const float*)nullptr,
                        (const float*)nullptr, (float*)nullptr, (float*)nullptr, stamps);

@@ -49,7 +49,9 @@ def build_index_maps():
     for li, (off_w, N, K, off_f, off_t) in enumerate(layers):
         n, k = np.meshgrid(np.arange(N), np.arange(K), indexing="ij")
         src = off_w + n * K + k
-        if li < 3:
+        if li == 1:     # layer 2 forward: two K=128 operands (k < 128, k >= 128), one per half of H1 in LDS
+            idx_f[src] = off_f + (k // (K // 2)) * (N * (K // 2)) + _frag_index(n, k % (K // 2), K // 2)
+        elif li < 3:
             idx_f[src] = off_f + _frag_index(n, k, K)
         else:       # layer 4 forward: split-K over the four waves
             w, h, kq, q = k // 32, (k % 32) // 16, (k % 16) // 4, k % 4

@@ -40,8 +40,8 @@ clk = (st[:, 13] - st[:, 0]) / np.maximum(real, 1) * 100e6
 print("in-kernel clock (s_memtime / s_memrealtime): median %.3f GHz, p10 %.3f, p90 %.3f" %
       (np.median(clk) / 1e9, np.percentile(clk, 10) / 1e9, np.percentile(clk, 90) / 1e9))
 d = np.diff(st, axis=1)
-names = ["x stage+barrier", "L1 gemm", "L1 epilogue", "L1 barrier", "copy H1", "L2 gemm", "L2 epilogue", "L2 barrier",
-         "copy H2", "L3 gemm", "L3 epilogue", "L3 barrier", "copy H3 + L4 + out"]
+names = ["x stage+barrier", "L1a gemm", "L1a epilogue", "barrier", "L2a + L1b gemms", "barrier + L1b epilogue", "barrier",
+         "L2b gemm", "L2 epilogue + barrier", "L3 gemm", "L3 epilogue", "barrier", "L4 + out"]
 tot = (st[:, 13] - st[:, 0])
 print("workgroups", grid, "mean total cycles per WG (s_memtime ticks = shader cycles)", tot.mean(), "median", np.median(tot))
 for i, nm in enumerate(names):
