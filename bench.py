@@ -96,12 +96,23 @@ def kernel_rooflines(num_envs, T, reps):
     p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
     s, d = pol.saves, pol.dz
     pol.minibatch_grad(x, act, olp, adv, tgt, var, 0.2)
-    t_fwd = _time_launches(lambda: lib.mlp_forward(p(pol.P), p(pol.PF), p(x), rows, None, None, p(s["out"]), p(s["h1"]),
-                                                    p(s["h2"]), p(s["h3"]), _lib.stream_ptr()), reps)
-    t_bwd = _time_launches(lambda: lib.mlp_backward_dx(p(pol.PT), p(s["out"]), p(s["h1"]), p(s["h2"]), p(s["h3"]),
-                                                       p(act), p(olp), p(adv), p(tgt), p(var), rows, 1.0 / rows, 0.2,
-                                                       p(d["dz4"]), p(d["dz3"]), p(d["dz2"]), p(d["dz1"]),
-                                                       p(pol.loss_part), _lib.stream_ptr()), reps)
+    flags = torch.zeros((rows + 31) // 32, dtype=torch.int32, device="cuda:0")
+    err = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+    epoch = [0]
+
+    def fwd_bwd():
+        epoch[0] += 1
+        lib.mlp_forward_backward(p(pol.P), p(pol.PF), p(pol.PT), p(x), rows, p(s["out"]), p(s["h1"]), p(s["h2"]), p(s["h3"]),
+                                 p(act), p(olp), p(adv), p(tgt), p(var), 1.0 / rows, 0.2, p(d["dz4"]), p(d["dz3"]),
+                                 p(d["dz2"]), p(d["dz1"]), p(pol.loss_part), p(flags), epoch[0], p(err), _lib.stream_ptr())
+    t_fb = _time_launches(fwd_bwd, reps)
+    assert int(err.item()) == 0, "mlp_forward_backward reported a lost tile flag"
+    xs = torch.randn(num_envs, 73, device="cuda:0")
+    eps = torch.randn(num_envs, 18, device="cuda:0")
+    a_o = torch.empty(num_envs, 18, device="cuda:0"); lp_o = torch.empty(num_envs, device="cuda:0")
+    v_o = torch.empty(num_envs, device="cuda:0")
+    t_pol = _time_launches(lambda: lib.mlp_forward_sample(p(pol.P), p(pol.PF), p(xs), num_envs, p(eps), p(var), p(a_o), p(lp_o),
+                                                          None, p(v_o), _lib.stream_ptr()), reps)
     t_gw = _time_launches(lambda: lib.mlp_grad_w(p(x), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(d["dz1"]), p(d["dz2"]),
                                                  p(d["dz3"]), p(d["dz4"]), rows, p(pol.workspace), p(pol.G), None, None, None,
                                                  _lib.stream_ptr()), reps)
@@ -121,12 +132,12 @@ def kernel_rooflines(num_envs, T, reps):
                 "avg_launch_us": round(dur * 1e6, 3), "algorithmic_per_launch": flop_per_launch,
                 "launches_per_iteration": per_iter, "iteration_share_ms": round(dur * per_iter * 1e3, 3)}
 
-    critic_rows = num_envs        # v(obs_t) falls out of the rollout launches; make_data evaluates the last next_obs only
-    fwd_equiv_launches = 75 + critic_rows / rows + T * num_envs / rows      # update + critic rows + rollout policy
     ks = [
         hbm("fly_kernel<63> (fly_step)", t_step, FUSED_STEP_BYTES_PER_ENV * num_envs, T),
-        mfma("mlp_forward_kernel", t_fwd, MLP_FWD_FLOP * rows, round(fwd_equiv_launches, 2)),
-        mfma("mlp_backward_dx_kernel", t_bwd, MLP_BWD_DX_FLOP * rows, 75),
+        # the update's forward + loss + dX chain of one 40 960-row minibatch is ONE launch
+        mfma("mlp_fwd_bwd_kernel", t_fb, (MLP_FWD_FLOP + MLP_BWD_DX_FLOP) * rows, 75),
+        # rollout policy + sampling (+ v(obs_t)) of num_envs rows, and once per iteration v(last next_obs)
+        mfma("mlp_forward_kernel (policy + sample, %d rows)" % num_envs, t_pol, MLP_FWD_FLOP * num_envs, T + 1),
         mfma("mlp_grad_w_kernel (+reduce)", t_gw, MLP_GRAD_W_FLOP * rows, 75),
         hbm("mlp_adam_kernel", t_adam, 74272 * 4 * 7, 75),
     ]
@@ -141,8 +152,7 @@ def kernel_rooflines(num_envs, T, reps):
     except Exception:
         traffic = {}
     grids = {"fly_kernel<63> (fly_step)": ("fly_kernel<63>", ((num_envs + 15) // 16) * 256),
-             "mlp_forward_kernel": ("mlp_forward_kernel", ((rows + 31) // 32) * 256),
-             "mlp_backward_dx_kernel": ("mlp_backward_dx_kernel", ((rows + 31) // 32) * 256),
+             "mlp_fwd_bwd_kernel": ("mlp_fwd_bwd_kernel", 2 * ((rows + 31) // 32) * 256),
              "mlp_grad_w_kernel (+reduce)": ("mlp_grad_w_kernel", 256 * 1024)}
     for k in ks:
         key = grids.get(k["kernel"])

@@ -175,9 +175,6 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NT])
 // Both tile kernels fit four workgroups per CU: <= 40 KB of LDS and <= 128 VGPRs each.
 constexpr int WGS_PER_CU = 4;
 constexpr int PERSIST_GRID = 256 * WGS_PER_CU;       // persistent launches: every slot of the chip
-#ifndef DEPHASE_SLEEP
-#define DEPHASE_SLEEP 95
-#endif
 constexpr int LDS_A_FLOATS = BM * (MLP_H2 + 4);      // one 128-column half of H1 at a time, later H3
 constexpr int LDS_B_FLOATS = BM * (MLP_H2 + 4);      // X0, later H2, later the split-K partials
 constexpr int LB1 = 0, LB2 = MLP_H1, LB3 = LB2 + MLP_H2, LB4 = LB3 + MLP_H3, LSD = LB4 + MLP_OUT, LLG = LSD + 32;
@@ -209,10 +206,10 @@ constexpr int XV = (BM * MLP_IN / 4 + THREADS - 1) / THREADS;       // float4 pe
 constexpr int FWD_LDS_FLOATS = LDS_A_FLOATS + LDS_B_FLOATS + LDS_C_FLOATS;
 
 // The body walks tiles first_tile, first_tile + tile_stride, ... (< ntiles) on the caller's LDS
-// arena; `slot` is the de-phasing delay of this workgroup (see below).
+// arena.
 template <bool STAMP>
 __device__ __forceinline__ void forward_body(
-    float* lds, const long first_tile, const long tile_stride, const int slot,
+    float* lds, const long first_tile, const long tile_stride,
     const float* __restrict__ P, const float* __restrict__ PF, const float* __restrict__ x, long n,
     float* __restrict__ mu_out, float* __restrict__ v_out, float* __restrict__ out_save,
     float* __restrict__ h1_save, float* __restrict__ h2_save, float* __restrict__ h3_save,
@@ -265,12 +262,6 @@ __device__ __forceinline__ void forward_body(
         }
     };
 
-    // De-phase the workgroups that share a CU.  They run the same program on the same clock, so
-    // without a nudge all three sit in their MFMA loops together (3x contention) and then in their
-    // epilogues together (matrix pipe idle).  Workgroups b, b+256, b+512 are the ones the dispatcher
-    // co-locates first; delaying the second and third by one and two thirds of a tile's solo time
-    // lets one group's epilogue hide under the others' MFMAs.  Speed only, never correctness.
-    for (int i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(DEPHASE_SLEEP);     // x 64 cycles each
     long tile = first_tile;
     if (tile < ntiles) x_load(tile);
     {   // biases (and the sampling constants) -> LDS once per workgroup; the first tile's barrier publishes them
@@ -425,7 +416,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_forward_kernel(
     float* __restrict__ smp_logp, unsigned long long* __restrict__ stamps_base)
 {
     __shared__ __attribute__((aligned(16))) float lds[FWD_LDS_FLOATS];
-    forward_body<STAMP>(lds, blockIdx.x, gridDim.x, (blockIdx.x >> 8) % WGS_PER_CU, P, PF, x, n, mu_out, v_out, out_save, h1_save,
+    forward_body<STAMP>(lds, blockIdx.x, gridDim.x, P, PF, x, n, mu_out, v_out, out_save, h1_save,
                         h2_save, h3_save, smp_eps, smp_var, smp_act, smp_logp, stamps_base);
 }
 
@@ -492,7 +483,7 @@ constexpr int BW_TAIL = BW_Z4 + BM * (MLP_OUT + 4);        // [32][2] per-row lo
 constexpr int BW_FLOATS = BW_TAIL + 2 * BM;                // 38.9 KB
 
 __device__ __forceinline__ void backward_body(
-    float* lds, const long tile, const int slot,
+    float* lds, const long tile,
     const float* __restrict__ PT, const float* __restrict__ out_saved, const float* __restrict__ h1_saved,
     const float* __restrict__ h2_saved, const float* __restrict__ h3_saved,
     const float* __restrict__ action, const float* __restrict__ old_logp, const float* __restrict__ adv,
@@ -507,8 +498,6 @@ __device__ __forceinline__ void backward_body(
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR: weight bases become scalar
     const long row0 = tile * BM;
 
-    // de-phase co-resident workgroups (see forward_body)
-    for (int i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(DEPHASE_SLEEP);
     WeightHead<1> wt4, wt3;
     gemm_prefetch<MLP_OUT, 1>(wt4, PT + MLP_OFF_TF4, wave, lane);
     HFrag<1> hf3;
@@ -602,7 +591,7 @@ __global__ __launch_bounds__(THREADS, WGS_PER_CU) void mlp_backward_dx_kernel(
     float* __restrict__ loss_part)
 {
     __shared__ __attribute__((aligned(16))) float lds[BW_FLOATS];
-    backward_body(lds, blockIdx.x, (blockIdx.x >> 8) % WGS_PER_CU, PT, out_saved, h1_saved, h2_saved, h3_saved, action,
+    backward_body(lds, blockIdx.x, PT, out_saved, h1_saved, h2_saved, h3_saved, action,
                   old_logp, adv, target, var, n, inv_batch, clip, dz4, dz3, dz2, dz1, loss_part);
 }
 
@@ -654,7 +643,7 @@ __global__ __launch_bounds__(THREADS, WGS_PER_CU) void mlp_fwd_bwd_kernel(
     if ((long)blockIdx.x < pad_tiles) {
         const long tile = blockIdx.x;
         if (tile >= tiles) return;
-        forward_body<false>(lds, tile, tiles, (blockIdx.x >> 8) % WGS_PER_CU, P, PF, x, n, nullptr, nullptr, out_save, h1_save,
+        forward_body<false>(lds, tile, tiles, P, PF, x, n, nullptr, nullptr, out_save, h1_save,
                             h2_save, h3_save, nullptr, nullptr, nullptr, nullptr, nullptr);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);                    // this thread's stores have been acknowledged by L2
@@ -684,7 +673,7 @@ __global__ __launch_bounds__(THREADS, WGS_PER_CU) void mlp_fwd_bwd_kernel(
         if (ok) return;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // ordering only: no cache maintenance (see above)
         if (STAMP && threadIdx.x == 0) stamps[4L * blockIdx.x + 2] = realtime_cu();
-        backward_body(lds, tile, 0, PT, out_save, h1_save, h2_save, h3_save, action, old_logp, adv, target, var, n, inv_batch,
+        backward_body(lds, tile, PT, out_save, h1_save, h2_save, h3_save, action, old_logp, adv, target, var, n, inv_batch,
                       clip, dz4, dz3, dz2, dz1, loss_part);
         if (STAMP && threadIdx.x == 0) {
             __builtin_amdgcn_s_waitcnt(0);
