@@ -138,28 +138,35 @@ __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8
 // store, and -- when `gdst` is given -- the same 16 bytes to the saved-activation rows in HBM.  A
 // wave's four stores of one column tile touch the same 32 lines (one 128-byte line per row) and
 // together fill them, so L2 merges them into full-line writes; no LDS read-back pass is needed.
+// `gtile` points at this tile's first row of the destination (a wave-uniform pointer); lanes
+// address it with small 32-bit offsets, and all stores sit under ONE predicate (`nvalid` rows of
+// the tile exist): 64-bit per-lane address arithmetic and per-store exec masking are issue slots
+// the matrix pipe does not get back.
 template <int N, int NT, int NG = N>
 __device__ __forceinline__ void epilogue_elu(const f32x16 (&acc)[NT], const float* __restrict__ bias, int col0,
-                                             float* lds_out, int lane, float* __restrict__ gdst, long row0, long nrows,
-                                             int gcol0 = 0)
+                                             float* lds_out, int lane, float* __restrict__ gtile, int nvalid)
 {
     const int r = lane & 31;
-    const bool st = gdst != nullptr && row0 + r < nrows;
-    float* grow = gdst + (row0 + r) * NG + gcol0;
+    float4 y[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int nb = col0 + 32 * t + acc_n(g, lane);
             const float4 bv = *reinterpret_cast<const float4*>(bias + nb);
-            float4 y;
-            y.x = elu(acc[t][4 * g + 0] + bv.x);
-            y.y = elu(acc[t][4 * g + 1] + bv.y);
-            y.z = elu(acc[t][4 * g + 2] + bv.z);
-            y.w = elu(acc[t][4 * g + 3] + bv.w);
-            *reinterpret_cast<float4*>(lds_out + r * (N + 4) + nb) = y;
-            if (st) *reinterpret_cast<float4*>(grow + nb) = y;
+            y[t][g].x = elu(acc[t][4 * g + 0] + bv.x);
+            y[t][g].y = elu(acc[t][4 * g + 1] + bv.y);
+            y[t][g].z = elu(acc[t][4 * g + 2] + bv.z);
+            y[t][g].w = elu(acc[t][4 * g + 3] + bv.w);
+            *reinterpret_cast<float4*>(lds_out + r * (N + 4) + nb) = y[t][g];
         }
+    }
+    if (gtile != nullptr && r < nvalid) {
+        float* grow = gtile + r * NG + col0 + acc_n(0, lane);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(grow + 32 * t + 8 * g) = y[t][g];
     }
 }
 
@@ -277,6 +284,10 @@ __device__ __forceinline__ void forward_body(
     }
     for (; tile < ntiles; tile += tile_stride) {
         const long row0 = tile * BM;
+        const int nvalid = (int)(n - row0 < BM ? n - row0 : BM);            // rows of this tile that exist
+        float* h1_tile = h1_save ? h1_save + row0 * MLP_H1 : nullptr;       // wave-uniform tile bases
+        float* h2_tile = h2_save ? h2_save + row0 * MLP_H2 : nullptr;
+        float* h3_tile = h3_save ? h3_save + row0 * MLP_H3 : nullptr;
         // opaque per-iteration copy of the thread index: keeps the dozens of tile-invariant LDS/global
         // offsets from being hoisted out of the tile loop (they would all be live across it and spill)
         int tl = tid;
@@ -307,7 +318,7 @@ __device__ __forceinline__ void forward_body(
             stamp<STAMP>(stamps, 2);
             gemm_prefetch<MLP_H2, 1>(w2a, PF + MLP_OFF_F2, wave, lane);           // both land during the epilogue
             gemm_prefetch<MLP_IN_PAD, 1>(w1b, PF + MLP_OFF_F1, 4 + wave, lane);
-            epilogue_elu<MLP_H2, 1, MLP_H1>(acc, ldsBias + LB1, wave * 32, ldsA, lane, h1_save, row0, n);
+            epilogue_elu<MLP_H2, 1, MLP_H1>(acc, ldsBias + LB1, wave * 32, ldsA, lane, h1_tile, nvalid);
         }
         stamp<STAMP>(stamps, 3);
         __syncthreads();
@@ -319,7 +330,7 @@ __device__ __forceinline__ void forward_body(
             stamp<STAMP>(stamps, 5);
             gemm_prefetch<MLP_H2, 1>(w2b, PF + MLP_OFF_F2 + MLP_H2 * (MLP_H1 / 2), wave, lane);
             __syncthreads();                                   // every wave has finished reading the first half of H1
-            epilogue_elu<MLP_H2, 1, MLP_H1>(acc, ldsBias + LB1 + MLP_H1 / 2, wave * 32, ldsA, lane, h1_save, row0, n, MLP_H1 / 2);
+            epilogue_elu<MLP_H2, 1, MLP_H1>(acc, ldsBias + LB1 + MLP_H1 / 2, wave * 32, ldsA, lane, h1_tile ? h1_tile + MLP_H1 / 2 : nullptr, nvalid);
         }
         stamp<STAMP>(stamps, 6);
         __syncthreads();
@@ -328,7 +339,7 @@ __device__ __forceinline__ void forward_body(
             tile_gemm<MLP_H2, 1, false>(w2b, PF + MLP_OFF_F2 + MLP_H2 * (MLP_H1 / 2), wave, ldsA, acc2, lane);
             stamp<STAMP>(stamps, 8);
             gemm_prefetch<MLP_H2, 1>(w3, PF + MLP_OFF_F3, wave, lane);
-            epilogue_elu<MLP_H2, 1>(acc2, ldsBias + LB2, wave * 32, ldsB, lane, h2_save, row0, n);   // x is dead: every wave passed the barrier above
+            epilogue_elu<MLP_H2, 1>(acc2, ldsBias + LB2, wave * 32, ldsB, lane, h2_tile, nvalid);   // x is dead: every wave passed the barrier above
         }
         __syncthreads();
         float4 w4[4];                                                            // layer-4 weights of this wave's k range
@@ -340,7 +351,7 @@ __device__ __forceinline__ void forward_body(
             const float* bp = PF + MLP_OFF_F4 + (wave * 4) * 256 + lane * 4;    // [wave][kq][lane][4]
 #pragma unroll
             for (int kq = 0; kq < 4; ++kq) w4[kq] = *reinterpret_cast<const float4*>(bp + 256 * kq);
-            epilogue_elu<MLP_H3, 1>(acc, ldsBias + LB3, wave * 32, ldsA, lane, h3_save, row0, n);
+            epilogue_elu<MLP_H3, 1>(acc, ldsBias + LB3, wave * 32, ldsA, lane, h3_tile, nvalid);
         }
         stamp<STAMP>(stamps, 11);
         __syncthreads();
@@ -372,29 +383,29 @@ __device__ __forceinline__ void forward_body(
             float z = ((ldsB[i] + ldsB[BM * MLP_OUT + i]) + ldsB[2 * BM * MLP_OUT + i]) + ldsB[3 * BM * MLP_OUT + i];
             z += ldsBias[LB4 + col];
             float y = (col < MLP_NACT) ? elu(z) : ((col == MLP_NACT) ? z : 0.0f);   // ELU on the mean (ppo.py:30), none on v
-            const long grow = row0 + row;
-            if (grow < n) {
-                if (out_save) out_save[grow * MLP_OUT + col] = y;
-                if (mu_out && col < MLP_NACT) mu_out[grow * MLP_NACT + col] = y;
-                if (v_out && col == MLP_NACT) v_out[grow] = y;
+            const bool in = row < nvalid;
+            if (in) {
+                if (out_save) (out_save + row0 * MLP_OUT)[i] = y;
+                if (mu_out && col < MLP_NACT) (mu_out + row0 * MLP_NACT)[row * MLP_NACT + col] = y;
+                if (v_out && col == MLP_NACT) (v_out + row0)[row] = y;
             }
             if (smp_eps) {
                 // ppo.py:215-220 fused: the 32 lanes that hold one output row sample its action
                 // (a = mu + sqrt(var) eps), reduce the Mahalanobis term and sum log L with a fixed
                 // xor-butterfly over the half-wave, and write the clipped action and the log-prob.
                 float x2 = 0.0f, lg = 0.0f, a = 0.0f;
-                const bool on = (col < MLP_NACT) && (grow < n);
+                const bool on = (col < MLP_NACT) && in;
                 if (on) {
                     const float L = ldsBias[LSD + col];
-                    a = y + L * smp_eps[grow * MLP_NACT + col];
+                    a = y + L * (smp_eps + row0 * MLP_NACT)[row * MLP_NACT + col];
                     const float xj = (a - y) / L;
                     x2 = xj * xj;
                     lg = ldsBias[LLG + col];
                 }
 #pragma unroll
                 for (int o = 1; o < 32; o <<= 1) { x2 += __shfl_xor(x2, o, 32); lg += __shfl_xor(lg, o, 32); }
-                if (on) smp_act[grow * MLP_NACT + col] = fminf(fmaxf(a, -1.0f), 1.0f);
-                if (col == 0 && grow < n) smp_logp[grow] = -0.5f * (33.08178959434617f + x2) - lg;
+                if (on) (smp_act + row0 * MLP_NACT)[row * MLP_NACT + col] = fminf(fmaxf(a, -1.0f), 1.0f);
+                if (col == 0 && in) (smp_logp + row0)[row] = -0.5f * (33.08178959434617f + x2) - lg;
             }
         }
         stamp<STAMP>(stamps, 13);
@@ -438,41 +449,48 @@ template <int NT>
 struct HFrag { float4 v[NT][4]; };
 
 template <int N, int NT>
-__device__ __forceinline__ void hfrag_load(HFrag<NT>& hf, const float* __restrict__ hsrc, long row0, long nrows, int col0,
-                                           int lane)
+__device__ __forceinline__ void hfrag_load(HFrag<NT>& hf, const float* __restrict__ htile, int nvalid, int col0, int lane)
 {
-    const long grow = row0 + (lane & 31);
-    const bool in = grow < nrows;
+    const int r = lane & 31;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            hf.v[t][g] = in ? *reinterpret_cast<const float4*>(hsrc + grow * N + col0 + 32 * t + acc_n(g, lane))
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = 0; g < 4; ++g) hf.v[t][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < nvalid) {
+        const float* hrow = htile + r * N + col0 + acc_n(0, lane);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) hf.v[t][g] = *reinterpret_cast<const float4*>(hrow + 32 * t + 8 * g);
+    }
 }
 
 // writes dZ to the gradient rows in HBM and (lds_out != nullptr) to the LDS tile the next GEMM reads
 template <int N, int NT>
 __device__ __forceinline__ void epilogue_dact(const f32x16 (&acc)[NT], const HFrag<NT>& hf, int col0, float* lds_out,
-                                              float* __restrict__ gdst, long row0, long nrows, int lane)
+                                              float* __restrict__ gtile, int nvalid, int lane)
 {
     const int r = lane & 31;
-    const bool st = row0 + r < nrows;
-    float* grow = gdst + (row0 + r) * N;
+    float4 z[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int nb = col0 + 32 * t + acc_n(g, lane);
             const float4 hv = hf.v[t][g];
-            float4 z;
-            z.x = acc[t][4 * g + 0] * elu_grad_from_out(hv.x);
-            z.y = acc[t][4 * g + 1] * elu_grad_from_out(hv.y);
-            z.z = acc[t][4 * g + 2] * elu_grad_from_out(hv.z);
-            z.w = acc[t][4 * g + 3] * elu_grad_from_out(hv.w);
-            if (lds_out) *reinterpret_cast<float4*>(lds_out + r * (N + 4) + nb) = z;
-            if (st) *reinterpret_cast<float4*>(grow + nb) = z;
+            z[t][g].x = acc[t][4 * g + 0] * elu_grad_from_out(hv.x);
+            z[t][g].y = acc[t][4 * g + 1] * elu_grad_from_out(hv.y);
+            z[t][g].z = acc[t][4 * g + 2] * elu_grad_from_out(hv.z);
+            z[t][g].w = acc[t][4 * g + 3] * elu_grad_from_out(hv.w);
+            if (lds_out) *reinterpret_cast<float4*>(lds_out + r * (N + 4) + nb) = z[t][g];
         }
+    }
+    if (r < nvalid) {
+        float* grow = gtile + r * N + col0 + acc_n(0, lane);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(grow + 32 * t + 8 * g) = z[t][g];
     }
 }
 
@@ -497,16 +515,23 @@ __device__ __forceinline__ void backward_body(
     float* rowloss = lds + BW_TAIL;                        // [32][2]: policy term, Huber term of each row
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR: weight bases become scalar
     const long row0 = tile * BM;
+    const int nvalid = (int)(n - row0 < BM ? n - row0 : BM);                // rows of this tile that exist
 
     WeightHead<1> wt4, wt3;
     gemm_prefetch<MLP_OUT, 1>(wt4, PT + MLP_OFF_TF4, wave, lane);
     HFrag<1> hf3;
-    hfrag_load<MLP_H3, 1>(hf3, h3_saved, row0, n, wave * 32, lane);     // in flight during the loss phase
+    hfrag_load<MLP_H3, 1>(hf3, h3_saved + row0 * MLP_H3, nvalid, wave * 32, lane);     // in flight during the loss phase
 
     // Loss gradient at the outputs, one thread per (row, output column): the 32 lanes of a row
     // reduce the Mahalanobis term and log-determinant with a fixed xor butterfly, every lane then
     // holds the row's d loss / d logp and writes its own column of dZ4 (HBM + the LDS operand).
     {
+        const float* out_t = out_saved + row0 * MLP_OUT;       // wave-uniform tile bases, 32-bit lane offsets
+        const float* act_t = action + row0 * MLP_NACT;
+        const float* olp_t = old_logp + row0;
+        const float* adv_t = adv + row0;
+        const float* tgt_t = target + row0;
+        float* dz4_t = dz4 + row0 * MLP_OUT;
         const int col = tid & 31;
         const bool act = col < MLP_NACT;
         const float L = act ? sqrtf(var[col]) : 1.0f;
@@ -517,10 +542,9 @@ __device__ __forceinline__ void backward_body(
 #pragma unroll
         for (int k = 0; k < BM * MLP_OUT / THREADS; ++k) {
             const int row = (tid >> 5) + k * (THREADS / 32);
-            const long g = row0 + row;
-            const bool in = g < n;
-            const float y = in ? out_saved[g * MLP_OUT + col] : 0.0f;                 // mean (cols 0..17), value (col 18)
-            const float a = (in && act) ? action[g * MLP_NACT + col] : 0.0f;
+            const bool in = row < nvalid;
+            const float y = in ? out_t[row * MLP_OUT + col] : 0.0f;                   // mean (cols 0..17), value (col 18)
+            const float a = (in && act) ? act_t[row * MLP_NACT + col] : 0.0f;
             const float xj = act ? (a - y) / L : 0.0f;
             float M = xj * xj;
 #pragma unroll
@@ -528,8 +552,8 @@ __device__ __forceinline__ void backward_body(
             float d = 0.0f, pol = 0.0f, hub = 0.0f;
             if (in) {
                 const float logp = -0.5f * (33.08178959434617f + M) - half_log_det;
-                const float ratio = expf(logp - old_logp[g]);
-                const float A = adv[g];
+                const float ratio = expf(logp - olp_t[row]);
+                const float A = adv_t[row];
                 const float s1 = ratio * A;
                 const float rc = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
                 const float s2 = rc * A;
@@ -540,11 +564,11 @@ __device__ __forceinline__ void backward_body(
                 else dmin = 0.5f * (A + A * in_range);
                 const float c = -inv_batch * ratio * dmin;     // d loss / d logp
                 pol = -fminf(s1, s2);
-                const float dv = __shfl(y, MLP_NACT, 32) - target[g];
+                const float dv = __shfl(y, MLP_NACT, 32) - tgt_t[row];
                 hub = fabsf(dv) < 1.0f ? 0.5f * dv * dv : fabsf(dv) - 0.5f;
                 if (act) d = c * (a - y) / var_col * elu_grad_from_out(y);
                 else if (col == MLP_NACT) d = inv_batch * fminf(fmaxf(dv, -1.0f), 1.0f);   // smooth_l1', beta = 1
-                dz4[g * MLP_OUT + col] = d;
+                dz4_t[row * MLP_OUT + col] = d;
             }
             ldsZ4[row * (MLP_OUT + 4) + col] = d;
             if (col == 0) { rowloss[2 * row] = pol; rowloss[2 * row + 1] = hub; }
@@ -561,8 +585,8 @@ __device__ __forceinline__ void backward_body(
         f32x16 acc[1];
         tile_gemm<MLP_OUT, 1>(wt4, PT + MLP_OFF_TF4, wave, ldsZ4, acc, lane);
         gemm_prefetch<MLP_H3, 1>(wt3, PT + MLP_OFF_TF3, wave, lane);          // both land during the epilogue + barrier
-        hfrag_load<MLP_H2, 1>(hf2, h2_saved, row0, n, wave * 32, lane);
-        epilogue_dact<MLP_H3, 1>(acc, hf3, wave * 32, ldsZ3, dz3, row0, n, lane);
+        hfrag_load<MLP_H2, 1>(hf2, h2_saved + row0 * MLP_H2, nvalid, wave * 32, lane);
+        epilogue_dact<MLP_H3, 1>(acc, hf3, wave * 32, ldsZ3, dz3 + row0 * MLP_H3, nvalid, lane);
     }
     __syncthreads();
     WeightHead<2> wt2;
@@ -571,14 +595,14 @@ __device__ __forceinline__ void backward_body(
         f32x16 acc[1];
         tile_gemm<MLP_H3, 1>(wt3, PT + MLP_OFF_TF3, wave, ldsZ3, acc, lane);
         gemm_prefetch<MLP_H2, 2>(wt2, PT + MLP_OFF_TF2, wave * 2, lane);
-        epilogue_dact<MLP_H2, 1>(acc, hf2, wave * 32, ldsZ2, dz2, row0, n, lane);
+        epilogue_dact<MLP_H2, 1>(acc, hf2, wave * 32, ldsZ2, dz2 + row0 * MLP_H2, nvalid, lane);
     }
     __syncthreads();
     {   // dA1 = dZ2 . W2  ->  dZ1 (no later GEMM reads it: HBM only)
-        hfrag_load<MLP_H1, 2>(hf1, h1_saved, row0, n, wave * 64, lane);       // lands during the MFMAs
+        hfrag_load<MLP_H1, 2>(hf1, h1_saved + row0 * MLP_H1, nvalid, wave * 64, lane);       // lands during the MFMAs
         f32x16 acc[2];
         tile_gemm<MLP_H2, 2>(wt2, PT + MLP_OFF_TF2, wave * 2, ldsZ2, acc, lane);
-        epilogue_dact<MLP_H1, 2>(acc, hf1, wave * 64, nullptr, dz1, row0, n, lane);
+        epilogue_dact<MLP_H1, 2>(acc, hf1, wave * 64, nullptr, dz1 + row0 * MLP_H1, nvalid, lane);
     }
 }
 
