@@ -162,6 +162,28 @@ class PackedPolicy:
         self.tile_wait_error = torch.zeros(1, dtype=torch.int32, device=dev)
         self._epoch = 0
         self.fuse_fwd_bwd = os.environ.get("FLY_FUSE_FWD_BWD", "1") != "0"
+        if self.fuse_fwd_bwd:
+            self._probe_fused_launch()
+
+    def _probe_fused_launch(self):
+        """mlp_forward_backward relies on a tile's forward and backward workgroups sharing an XCD (its
+        err word says if they do not).  One small launch over 64 tiles (8 per XCD) at start-up decides:
+        on a device that places workgroups differently the two-launch path is used instead --
+        same results, the kernel never guesses."""
+        n = min(self.max_rows, 64 * 32)
+        z = lambda *shape: torch.zeros(*shape, device=self.device)   # noqa: E731
+        self.minibatch_grad(z(n, IN), z(n, NACT), z(n), z(n), z(n), torch.full((NACT,), 0.2, device=self.device), 0.2)
+        self.check_fused_launch()
+
+    def check_fused_launch(self):
+        """Host sync.  Raises if a fused launch lost a tile flag (results of that call are invalid);
+        switches to the two-launch path if the device does not co-locate producer and consumer."""
+        err = int(self.tile_wait_error.item())
+        if err == 2:
+            self.fuse_fwd_bwd = False
+            self.tile_wait_error.zero_()
+        elif err != 0:
+            raise _lib.FlyHipError("mlp_forward_backward: a backward workgroup gave up waiting for its tile (err=%d)" % err)
 
     def minibatch_grad(self, x, action, old_logp, adv, target, var, clip, global_rows=None, fuse_norm=False):
         """Forward + loss + backward of one minibatch; leaves the packed gradient in `self.G`.

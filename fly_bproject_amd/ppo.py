@@ -260,6 +260,10 @@ class PPO:
                 pol.adam_step(grad_scale=1.0 / self.world_size if sync_grads else 1.0, norm_ready=not sync_grads)
                 self.optim_step += 1
                 k = j
+        if pol.fuse_fwd_bwd:
+            pol.check_fused_launch()            # one host sync per update: a lost tile flag must never go unnoticed
+            if not pol.fuse_fwd_bwd:
+                raise _lib.FlyHipError("mlp_forward_backward: producer and consumer workgroups on different XCDs mid-run")
         if self.world_size > 1 and not sync_grads:
             # dp_mode "param_average": ONE exchange per PPO update (BASELINE's north_star wording) --
             # ranks take their 75 optimizer steps locally, then parameters and Adam moments are
