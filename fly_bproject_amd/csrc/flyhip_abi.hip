@@ -48,7 +48,8 @@ extern "C" hipError_t flyhip_launch_dqn_huber_td(const float* q_table, const flo
                                                  float* dq, float* loss_part, void* stream);
 
 extern "C" hipError_t flyhip_launch_mlp_forward_sample(const float* P, const float* PF, const float* x, int64_t n,
-                                                       const float* eps, const float* var, float* act_out,
+                                                       const float* eps, const float* var, int var_steps,
+                                                       float var_decay, float var_min, float* act_out,
                                                        float* logp_out, float* mu_out, float* v_out, void* stream);
 
 extern "C" hipError_t flyhip_launch_mlp_fwd_bwd(const float* P, const float* PF, const float* PT, const float* x, int64_t n,
@@ -57,6 +58,9 @@ extern "C" hipError_t flyhip_launch_mlp_fwd_bwd(const float* P, const float* PF,
                                                 const float* target, const float* var, float inv_batch, float clip,
                                                 float* dz4, float* dz3, float* dz2, float* dz1, float* loss_part,
                                                 int* flags, int epoch, int* err, void* stream);
+extern "C" hipError_t flyhip_launch_rollout_bookkeeping(const float* reward, int64_t rows, int64_t n, float* terms,
+                                                        float* score_acc, float score_scale, float* action_var, int nvar,
+                                                        float var_decay, float var_min, void* stream);
 extern "C" hipError_t flyhip_launch_adv_stats(const float* adv, int64_t n, float* stats, void* stream);
 extern "C" hipError_t flyhip_launch_adv_apply(float* adv, int64_t n, const float* totals, float count, float eps, void* stream);
 
@@ -121,7 +125,7 @@ int launch(FlyHandle h, int phases, const float* actions, const FlyBuffers* b, v
 extern "C" {
 
 const char* fly_last_error(void) { return g_err; }
-int fly_abi_version(void) { return 2; }
+int fly_abi_version(void) { return 3; }
 
 int fly_create(const FlyConfig* cfg, FlyHandle* out)
 {
@@ -215,6 +219,19 @@ int ppo_adv_apply(float* adv, int64_t n, const float* totals, float count, float
     return FLY_OK;
 }
 
+int ppo_rollout_bookkeeping(const float* reward, int64_t rows, int64_t n, float* terms, float* score_acc,
+                            float score_scale, float* action_var, int32_t nvar, float var_decay,
+                            float var_min, void* stream)
+{
+    if (!reward || !terms || !score_acc || !action_var) return fail(FLY_E_ARG, "ppo_rollout_bookkeeping: null pointer");
+    if (rows < 0 || n <= 0 || nvar < 0 || nvar > 63) return fail(FLY_E_ARG, "ppo_rollout_bookkeeping: bad size");
+    if (rows == 0) return FLY_OK;
+    hipError_t e = flyhip_launch_rollout_bookkeeping(reward, rows, n, terms, score_acc, score_scale, action_var, nvar,
+                                                     var_decay, var_min, stream);
+    if (e != hipSuccess) return hip_fail(e, "ppo_rollout_bookkeeping launch");
+    return FLY_OK;
+}
+
 int ppo_step_bookkeeping(const float* reward, int64_t n, float* score_acc, float score_scale,
                          float* action_var, int32_t nvar, float var_decay, float var_min, void* stream)
 {
@@ -237,13 +254,16 @@ int mlp_forward(const float* params, const float* params_frag, const float* x, i
 }
 
 int mlp_forward_sample(const float* params, const float* params_frag, const float* x, int64_t n,
-                       const float* eps, const float* var, float* act_out, float* logp_out,
-                       float* mu_out, float* v_out, void* stream)
+                       const float* eps, const float* var, int32_t var_steps, float var_decay,
+                       float var_min, float* act_out, float* logp_out, float* mu_out, float* v_out,
+                       void* stream)
 {
     if (!params || !params_frag || !x || !eps || !var || !act_out || !logp_out)
         return fail(FLY_E_ARG, "mlp_forward_sample: null pointer");
     if (n <= 0) return fail(FLY_E_ARG, "mlp_forward_sample: n must be > 0");
-    hipError_t e = flyhip_launch_mlp_forward_sample(params, params_frag, x, n, eps, var, act_out, logp_out, mu_out, v_out, stream);
+    if (var_steps < 0 || var_steps > (1 << 20)) return fail(FLY_E_ARG, "mlp_forward_sample: var_steps out of range");
+    hipError_t e = flyhip_launch_mlp_forward_sample(params, params_frag, x, n, eps, var, var_steps, var_decay, var_min, act_out, logp_out,
+                                                    mu_out, v_out, stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_forward_sample launch");
     return FLY_OK;
 }

@@ -221,7 +221,8 @@ __device__ __forceinline__ void forward_body(
     float* __restrict__ mu_out, float* __restrict__ v_out, float* __restrict__ out_save,
     float* __restrict__ h1_save, float* __restrict__ h2_save, float* __restrict__ h3_save,
     const float* __restrict__ smp_eps, const float* __restrict__ smp_var, float* __restrict__ smp_act,
-    float* __restrict__ smp_logp, unsigned long long* __restrict__ stamps_base)
+    float* __restrict__ smp_logp, unsigned long long* __restrict__ stamps_base,
+    const int smp_var_steps = 0, const float smp_var_decay = 0.0f, const float smp_var_min = 0.0f)
 {
     unsigned long long* stamps = stamps_base;
     float* ldsA = lds;
@@ -277,7 +278,9 @@ __device__ __forceinline__ void forward_body(
         else ldsBias[LB3 + tid - MLP_H2] = P[MLP_OFF_B3 + tid - MLP_H2];
         if (tid < MLP_OUT) ldsBias[LB4 + tid] = P[MLP_OFF_B4 + tid];
         if (smp_var && tid >= 64 && tid < 64 + MLP_NACT) {
-            const float L = sqrtf(smp_var[tid - 64]);
+            float v = smp_var[tid - 64];
+            for (int i = 0; i < smp_var_steps; ++i) v = fmaxf(smp_var_min, v - smp_var_decay);   // ppo.py:236-237, not yet applied to the tensor
+            const float L = sqrtf(v);
             ldsBias[LSD + tid - 64] = L;
             ldsBias[LLG + tid - 64] = logf(L);
         }
@@ -424,11 +427,13 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_forward_kernel(
     float* __restrict__ mu_out, float* __restrict__ v_out, float* __restrict__ out_save,
     float* __restrict__ h1_save, float* __restrict__ h2_save, float* __restrict__ h3_save,
     const float* __restrict__ smp_eps, const float* __restrict__ smp_var, float* __restrict__ smp_act,
-    float* __restrict__ smp_logp, unsigned long long* __restrict__ stamps_base)
+    float* __restrict__ smp_logp, unsigned long long* __restrict__ stamps_base, int smp_var_steps, float smp_var_decay,
+    float smp_var_min)
 {
     __shared__ __attribute__((aligned(16))) float lds[FWD_LDS_FLOATS];
     forward_body<STAMP>(lds, blockIdx.x, gridDim.x, P, PF, x, n, mu_out, v_out, out_save, h1_save,
-                        h2_save, h3_save, smp_eps, smp_var, smp_act, smp_logp, stamps_base);
+                        h2_save, h3_save, smp_eps, smp_var, smp_act, smp_logp, stamps_base, smp_var_steps, smp_var_decay,
+                        smp_var_min);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1089,19 +1094,20 @@ extern "C" hipError_t flyhip_launch_mlp_forward(const float* P, const float* PF,
     const int grid = (int)(tiles <= 4 * PERSIST_GRID ? tiles : PERSIST_GRID);
     hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PF, x, (long)n,
                        mu_out, v_out, out_save, h1_save, h2_save, h3_save, (const float*)nullptr, (const float*)nullptr,
-                       (float*)nullptr, (float*)nullptr, (unsigned long long*)nullptr);
+                       (float*)nullptr, (float*)nullptr, (unsigned long long*)nullptr, 0, 0.0f, 0.0f);
     return hipGetLastError();
 }
 
 extern "C" hipError_t flyhip_launch_mlp_forward_sample(const float* P, const float* PF, const float* x, int64_t n,
-                                                       const float* eps, const float* var, float* act_out,
+                                                       const float* eps, const float* var, int var_steps,
+                                                       float var_decay, float var_min, float* act_out,
                                                        float* logp_out, float* mu_out, float* v_out, void* stream)
 {
     const long tiles = (n + BM - 1) / BM;
     const int grid = (int)(tiles <= 4 * PERSIST_GRID ? tiles : PERSIST_GRID);
     hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PF, x, (long)n,
                        mu_out, v_out, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, eps,
-                       var, act_out, logp_out, (unsigned long long*)nullptr);
+                       var, act_out, logp_out, (unsigned long long*)nullptr, var_steps, var_decay, var_min);
     return hipGetLastError();
 }
 
@@ -1114,7 +1120,7 @@ extern "C" int flyhip_debug_mlp_forward_stamped(const float* P, const float* PF,
     const int grid = grid_override > 0 ? grid_override : (int)(tiles <= 4 * PERSIST_GRID ? tiles : PERSIST_GRID);
     hipLaunchKernelGGL(mlp_forward_kernel<true>, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PF, x, (long)n,
                        (float*)nullptr, (float*)nullptr, out_save, h1_save, h2_save, h3_save, (const float*)nullptr,
-                       (const float*)nullptr, (float*)nullptr, (float*)nullptr, stamps);
+                       (const float*)nullptr, (float*)nullptr, (float*)nullptr, stamps, 0, 0.0f, 0.0f);
     return (int)hipGetLastError();
 }
 

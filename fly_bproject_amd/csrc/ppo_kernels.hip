@@ -224,7 +224,66 @@ __global__ __launch_bounds__(1024) void ppo_bookkeeping_kernel(const float* __re
     if (tid < nvar && var_decay > 0.0f) action_var[tid] = fmaxf(var_min, action_var[tid] - var_decay);
 }
 
+// The same bookkeeping for `rows` consecutive env steps at once (reward [rows][n]), bit for bit what
+// `rows` calls of the kernel above leave: one workgroup per row computes that row's score term with
+// the identical reduction, a second single-wave launch adds the terms in row order and applies the
+// variance decay `rows` times.  The rollout calls this when the score is printed and before an
+// update instead of paying a latency-bound single-workgroup launch on every env step.
+__global__ __launch_bounds__(1024) void ppo_row_terms_kernel(const float* __restrict__ reward, long n, float score_scale,
+                                                             float* __restrict__ terms)
+{
+    __shared__ float red[16];
+    const int tid = threadIdx.x;
+    const float* row = reward + (long)blockIdx.x * n;
+    float s = 0.0f;
+    const long n4 = n >> 2;
+    const float4* r4 = reinterpret_cast<const float4*>(row);
+    const bool aligned = (reinterpret_cast<uintptr_t>(row) & 15) == 0;
+    if (aligned) {
+        for (long i = tid; i < n4; i += 1024) { const float4 v = r4[i]; s += (v.x + v.y) + (v.z + v.w); }
+        for (long i = 4 * n4 + tid; i < n; i += 1024) s += row[i];
+    } else {
+        for (long i = tid; i < n; i += 1024) s += row[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.0f;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        terms[blockIdx.x] = t / (float)n * score_scale;
+    }
+}
+
+__global__ __launch_bounds__(64) void ppo_rows_apply_kernel(const float* __restrict__ terms, long rows,
+                                                            float* __restrict__ score_acc, float* __restrict__ action_var,
+                                                            int nvar, float var_decay, float var_min)
+{
+    const int tid = threadIdx.x;
+    if (tid == 63) {
+        float acc = *score_acc;
+        for (long r = 0; r < rows; ++r) acc += terms[r];
+        *score_acc = acc;
+    }
+    if (tid < nvar && var_decay > 0.0f) {
+        float v = action_var[tid];
+        for (long r = 0; r < rows; ++r) v = fmaxf(var_min, v - var_decay);
+        action_var[tid] = v;
+    }
+}
+
 }  // namespace
+
+extern "C" hipError_t flyhip_launch_rollout_bookkeeping(const float* reward, int64_t rows, int64_t n, float* terms,
+                                                        float* score_acc, float score_scale, float* action_var, int nvar,
+                                                        float var_decay, float var_min, void* stream)
+{
+    hipLaunchKernelGGL(ppo_row_terms_kernel, dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream, reward, (long)n,
+                       score_scale, terms);
+    hipLaunchKernelGGL(ppo_rows_apply_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, terms, (long)rows, score_acc,
+                       action_var, nvar, var_decay, var_min);
+    return hipGetLastError();
+}
 
 extern "C" hipError_t flyhip_launch_bookkeeping(const float* reward, int64_t n, float* score_acc, float score_scale,
                                                 float* action_var, int nvar, float var_decay, float var_min,

@@ -130,7 +130,14 @@ class PPO:
         self.update_backend = getattr(args, "update_backend", "hip")
         self.policy.init_training(self.mini_chunk_size * n, lr=self.lr)
         action_var = 0.01 if self.args.testing else 0.2             # ppo.py:152
-        self.action_var = torch.full((self.env.num_act,), action_var, device=dev)
+        # ppo.py:236-237 decays the variance after every env step and ppo.py:233 adds the step's mean
+        # reward to the score.  Both are applied to the device tensors LAZILY, for a run of steps at
+        # once (`_flush_bookkeeping`): when the score is printed, before an update, and whenever
+        # `action_var` is read; in between the policy launch derives the step's variance from the
+        # tensor and the number of pending decays.  Bit for bit the per-step result.
+        self._action_var = torch.full((self.env.num_act,), action_var, device=dev)
+        self._book_from = 0            # first rollout row whose bookkeeping is still pending
+        self._rows_done = 0            # rollout rows stepped so far in this rollout
         self.optim = torch.optim.Adam(self.net.parameters(), lr=self.lr)
 
         self._lib = _lib.load()
@@ -161,6 +168,29 @@ class PPO:
         self._all_done = value
 
     # ------------------------------------------------------------------------------------------
+    @property
+    def action_var(self):
+        if getattr(self, "_book_terms", None) is not None:
+            self._flush_bookkeeping()
+        return self._action_var
+
+    @action_var.setter
+    def action_var(self, value):
+        self._action_var = value
+
+    def _flush_bookkeeping(self):
+        """Apply the score terms and variance decays of rollout rows [_book_from, _rows_done)."""
+        rows = self._rows_done - self._book_from
+        if rows <= 0:
+            return
+        n = int(self.args.num_envs)
+        P = C.c_void_p
+        _lib.check(self._lib.ppo_rollout_bookkeeping(
+            P(self.all_reward[self._book_from].data_ptr()), C.c_int64(rows), C.c_int64(n), P(self._book_terms.data_ptr()),
+            P(self._score_acc.data_ptr()), C.c_float(1.0 / self.num_eval_freq), P(self._action_var.data_ptr()),
+            C.c_int(self.num_acts), C.c_float(self._var_decay), self._var_min, _lib.stream_ptr()), "ppo_rollout_bookkeeping")
+        self._book_from = self._rows_done
+
     def make_data(self):
         """ppo.py:157-171: TD target and GAE.  `all_done` is the [N,1] mask of the LAST step,
         broadcast over T (Q1), and the recurrence never resets at episode ends (Q2)."""
@@ -208,7 +238,7 @@ class PPO:
         clipped action under the current (decayed) variance (Q6); the Huber term is a scalar
         mean added to every element (Q7)."""
         mu = self.net.pi(obs_mc)
-        log_prob = diag_gauss_logprob(mu, action_mc, self.action_var)
+        log_prob = diag_gauss_logprob(mu, action_mc, self._action_var)
         ratio = torch.exp(log_prob - old_log_prob_mc).unsqueeze(-1)
         surr1 = ratio * advantage_mc
         surr2 = torch.clamp(ratio, 1 - self.clip, 1 + self.clip) * advantage_mc
@@ -253,7 +283,7 @@ class PPO:
             for j in range(mc, self.rollout_size, mc):
                 pol.minibatch_grad(obs[k:j].view(rows, self.num_obs), action[k:j].view(rows, self.num_acts),
                                    old_log_prob[k:j].view(rows), advantage[k:j].view(rows),
-                                   target[k:j].view(rows), self.action_var, self.clip,
+                                   target[k:j].view(rows), self._action_var, self.clip,
                                    fuse_norm=not sync_grads)
                 if sync_grads:
                     dist.all_reduce(pol.G, op=dist.ReduceOp.SUM)    # 297 KB, latency-bound on xGMI
@@ -286,23 +316,33 @@ class PPO:
         self._reward_rows = [self.all_reward[t].view(-1) for t in range(T)]
         self._act_rows = [self.all_acts[t] for t in range(T)]
         fwd, book, bufs = [], [], []
+        self._var_decay = 0.0 if self.args.testing else 0.00001     # ppo.py:236
+        self._var_min = C.c_float(0.01)
+        self._var_steps = C.c_int(0)                                 # pending decays, set before every policy launch
+        self._book_terms = torch.zeros(T, device=self.device)       # scratch of ppo_rollout_bookkeeping
+        self._lazy_book = not self.use_graph                         # captured launches freeze their arguments
+        var_ptr = P(self._action_var.data_ptr())
         for t in range(T):
             fwd.append((P(pol.P.data_ptr()), P(pol.PF.data_ptr()), P(self._obs_rows[t].data_ptr()), C.c_int64(n),
-                        P(self._eps_all[t].data_ptr()), P(self.action_var.data_ptr()), P(self._act_rows[t].data_ptr()),
-                        P(self.all_log_prob[t].data_ptr()), None, P(self._v_ring[t].data_ptr())))
+                        P(self._eps_all[t].data_ptr()), var_ptr, self._var_steps, C.c_float(self._var_decay), self._var_min,
+                        P(self._act_rows[t].data_ptr()), P(self.all_log_prob[t].data_ptr()), None,
+                        P(self._v_ring[t].data_ptr())))
             book.append((P(self._reward_rows[t].data_ptr()), C.c_int64(n), P(self._score_acc.data_ptr()),
-                         C.c_float(1.0 / self.num_eval_freq), P(self.action_var.data_ptr()), C.c_int(self.num_acts)))
+                         C.c_float(1.0 / self.num_eval_freq), var_ptr, C.c_int(self.num_acts)))
             bufs.append((self._obs_rows[t + 1].data_ptr(), self._reward_rows[t].data_ptr()))
         self._fwd_args, self._book_args, self._buf_ptrs = fwd, book, bufs
-        self._var_min = C.c_float(0.01)
 
     def _launch_step(self, t):
-        """The device work of one env step (ppo.py:213-237): three launches, no host logic.  Rows of
-        the rollout are written in place (obs row t+1, action/log-prob/reward rows t)."""
+        """The device work of one env step (ppo.py:213-237): two launches, no host logic.  Rows of
+        the rollout are written in place (obs row t+1, action/log-prob/reward rows t); the score and
+        variance bookkeeping of the step is deferred (`_flush_bookkeeping`)."""
         lib, env = self._lib, self.env
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         if t == 0:
             self._eps_all.normal_(generator=self._gen)              # the eps of MultivariateNormal.sample, whole rollout
+        if t == 0:
+            self._rows_done = self._book_from = 0
+        self._var_steps.value = (t - self._book_from) if self._lazy_book else 0
         rc = lib.mlp_forward_sample(*self._fwd_args[t], st)         # ppo.py:214-220, :227 (policy + sampling fused)
         if t == 0:
             self._v_have, self._v_version = 1, self.policy.version
@@ -311,9 +351,11 @@ class PPO:
         env.obs_buf, env.reward_buf = self._obs_rows[t + 1], self._reward_rows[t]      # ppo.py:228-229
         env._bufs.obs, env._bufs.reward = self._buf_ptrs[t]
         rc |= lib.fly_step(env._handle, C.c_void_p(self._act_rows[t].data_ptr()), C.byref(env._bufs), st)  # ppo.py:223
-        # ppo.py:230 (all_done): see the property.  ppo.py:233 + :236-237 in one tiny launch:
-        rc |= lib.ppo_step_bookkeeping(*self._book_args[t], C.c_float(0.0 if self.args.testing else 0.00001),
-                                       self._var_min, st)
+        # ppo.py:230 (all_done): see the property.  ppo.py:233 + :236-237: deferred, or one tiny launch
+        if self._lazy_book:
+            self._rows_done = t + 1
+        else:
+            rc |= lib.ppo_step_bookkeeping(*self._book_args[t], C.c_float(self._var_decay), self._var_min, st)
         if rc:
             _lib.check(rc, "rollout step")
         env.render_count += 1
@@ -344,6 +386,7 @@ class PPO:
                 g.replay()
 
         if t + 1 == self.rollout_size:                              # ppo.py:240-252
+            self._flush_bookkeeping()                               # the update reads the decayed variance
             if not self.args.testing:
                 print("Training")
                 self.update()
@@ -359,11 +402,12 @@ class PPO:
             self.mini_batch_number += 1
 
         if self.run_step % self.num_eval_freq == 0:                 # ppo.py:257-260
+            self._flush_bookkeeping()
             self.score = float(self._score_acc.item())
             self._score_acc.zero_()
             if int(getattr(self.args, "rank", 0)) == 0:
                 print('Steps: {:04d} | Opt Step: {:04d} | Reward {:.04f} | Action Var {:.04f}'
-                      .format(self.run_step, self.optim_step, self.score, self.action_var[0].item()))
+                      .format(self.run_step, self.optim_step, self.score, self._action_var[0].item()))
             self.score = 0
 
         self.run_step += 1

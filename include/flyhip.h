@@ -188,6 +188,15 @@ int ppo_adv_apply(float* adv, int64_t n, const float* totals, float count, float
 int ppo_step_bookkeeping(const float* reward, int64_t n, float* score_acc, float score_scale,
                          float* action_var, int32_t nvar, float var_decay, float var_min, void* stream);
 
+/* The same bookkeeping for `rows` consecutive env steps in two small launches, bit for bit what
+ * `rows` calls of ppo_step_bookkeeping on the rows of reward f32 [rows][n] leave (score terms are
+ * added in row order, the variance is decayed `rows` times).  `terms` is a device scratch of
+ * >= rows floats.  The rollout calls it when the score is printed and before an update instead of
+ * launching the per-step form on every env step. */
+int ppo_rollout_bookkeeping(const float* reward, int64_t rows, int64_t n, float* terms, float* score_acc,
+                            float score_scale, float* action_var, int32_t nvar, float var_decay,
+                            float var_min, void* stream);
+
 /*
  * Actor-critic MLP on the matrix cores (fp32-in/fp32-accumulate MFMA), reference ppo.py:10-102
  * (`Net.pi` / `Net.v`; 73-256-128 shared trunk, 128-64-18 actor with ELU on the mean, 128-64-1
@@ -207,10 +216,14 @@ int mlp_forward(const float* params, const float* params_frag, const float* x, i
 /* ppo.py:214-220 in ONE launch: mu = Net.pi(x), act = mu + sqrt(var)*eps, log-prob of the unclipped
  * act, act_out = clip(act, -1, 1).  eps, act_out f32 [n][18]; var f32 [18]; logp_out f32 [n];
  * mu_out f32 [n][18] and v_out f32 [n] (= Net.v(x), the same rows the critic pass of ppo.py:158-159
- * would recompute with unchanged weights) are optional. */
+ * would recompute with unchanged weights) are optional.  The variance used is `var` after
+ * `var_steps` applications of v <- max(var_min, v - var_decay) (ppo.py:236-237), computed in the
+ * kernel without touching `var`: the caller may apply the decays of a whole rollout to the tensor
+ * later (ppo_rollout_bookkeeping).  var_steps = 0 uses `var` as is. */
 int mlp_forward_sample(const float* params, const float* params_frag, const float* x, int64_t n,
-                       const float* eps, const float* var, float* act_out, float* logp_out,
-                       float* mu_out, float* v_out, void* stream);
+                       const float* eps, const float* var, int32_t var_steps, float var_decay,
+                       float var_min, float* act_out, float* logp_out, float* mu_out, float* v_out,
+                       void* stream);
 
 
 /*

@@ -177,7 +177,7 @@ def test_fused_forward_sample_matches_separate_kernels(n):
     _lib.check(lib.ppo_sample_logprob(p(mu), p(var), p(eps), p(act1), p(lp1), n, None), "sample")
     act2 = torch.empty(n, 18, device="cuda:0"); lp2 = torch.empty(n, device="cuda:0"); mu2 = torch.empty(n, 18, device="cuda:0")
     v2 = torch.empty(n, device="cuda:0")
-    _lib.check(lib.mlp_forward_sample(p(pol.P), p(pol.PF), p(x), n, p(eps), p(var), p(act2), p(lp2), p(mu2), p(v2), None), "fused")
+    _lib.check(lib.mlp_forward_sample(p(pol.P), p(pol.PF), p(x), n, p(eps), p(var), 0, 0.0, 0.0, p(act2), p(lp2), p(mu2), p(v2), None), "fused")
     torch.cuda.synchronize()
     assert torch.equal(mu, mu2) and torch.equal(act1, act2) and torch.equal(v1.view(-1), v2)
     torch.testing.assert_close(lp1, lp2, rtol=2e-6, atol=1e-5)
@@ -213,3 +213,27 @@ def test_reference_default_env_count():
     assert torch.isfinite(agent._obs_ring).all() and torch.isfinite(agent.policy.P).all()
     assert torch.all(agent.policy.W1[:, 73:] == 0)
     agent.exit()
+
+
+def test_rollout_bookkeeping_equals_per_step_calls():
+    """ppo_rollout_bookkeeping over a block of rows == ppo_step_bookkeeping row by row, bit for bit
+    (score terms added in row order, variance decayed once per row, clamp included)."""
+    import ctypes as C
+    from fly_bproject_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(5)
+    rows, n = 37, 8192
+    reward = torch.randn(rows, n, device="cuda:0")
+    p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    for dec, v0 in ((1e-5, 0.2), (1e-3, 0.02), (0.0, 0.2)):
+        s1 = torch.full((), 0.25, device="cuda:0"); v1 = torch.full((18,), v0, device="cuda:0")
+        for r in range(rows):
+            _lib.check(lib.ppo_step_bookkeeping(p(reward[r]), n, p(s1), C.c_float(0.01), p(v1), 18, C.c_float(dec),
+                                                C.c_float(0.01), None), "step")
+        s2 = torch.full((), 0.25, device="cuda:0"); v2 = torch.full((18,), v0, device="cuda:0")
+        terms = torch.zeros(rows, device="cuda:0")
+        _lib.check(lib.ppo_rollout_bookkeeping(p(reward), rows, n, p(terms), p(s2), C.c_float(0.01), p(v2), 18,
+                                               C.c_float(dec), C.c_float(0.01), None), "rollout")
+        torch.cuda.synchronize()
+        assert torch.equal(s1, s2) and torch.equal(v1, v2)
+    assert float(v2[0]) == float(np.float32(0.2))            # dec = 0: untouched
