@@ -5,14 +5,18 @@
 // (:482-485, build-defined FlyDyn), K4 observation pack (:771-805),
 // progress += 1 (:678), K5 reward/done pack (:685-768).
 //
-// Mapping (CDNA4, 64-wide waves): 16 lanes own one env, so a wave carries 4 envs and a
-// 256-thread workgroup 16.  Inside an env's 16-lane DPP row
-//     lanes 0..5   one leg each: 3 PD joints, leg kinematics, tip contact
-//     lanes 6..10  one abdomen contact point each
-//     lanes 11..15 idle in the contact pass (they still hold the replicated root state)
-// The body wrench is an all-reduce over the row with four DPP adds per component
-// (quad_perm xor1, quad_perm xor2, row_half_mirror, row_mirror); the tree is symmetric so all
-// 16 lanes end with bit-identical sums and integrate the replicated root state identically.
+// Mapping (CDNA4, 64-wide waves): 8 lanes own one env, so a wave carries 8 envs and a
+// 256-thread workgroup 32.  Inside an env's 8-lane half of a DPP row
+//     lanes 0..5   one leg each: 3 PD joints, leg kinematics, tip contact        (contact pass A)
+//     lanes 0..4   ALSO one abdomen contact point each                          (contact pass B)
+//     lanes 6..7   idle in the contact passes (they still hold the replicated root state)
+// The kernel is VALU-issue-bound (15 substeps x ~400 instructions per wave), so what counts is
+// instructions per env: the contact code runs twice per substep, but a wave now advances 8 envs
+// instead of 4 -- 1.5x fewer instructions per env-substep than one point per lane on 16 lanes
+// (11 of 16 lanes busy, root integration replicated 16x).
+// The body wrench is an all-reduce over the 8 lanes with three DPP adds per component
+// (quad_perm xor1, quad_perm xor2, row_half_mirror); the tree is symmetric so all 8 lanes end
+// with bit-identical sums and integrate the replicated root state identically.
 // All role differences are selects, not branches: a wave never diverges inside the substep loop.
 // Substeps run in registers; HBM is touched once on the way in and once on the way out.
 // Observation rows (row-major [N][73], a GEMM operand for the policy) are assembled in an LDS
@@ -23,7 +27,7 @@
 
 namespace {
 
-constexpr int LANES_PER_ENV = 16;
+constexpr int LANES_PER_ENV = 8;
 constexpr int BLOCK = 256;
 constexpr int ENVS_PER_BLOCK = BLOCK / LANES_PER_ENV;
 
@@ -39,13 +43,12 @@ __device__ __forceinline__ int dpp_i(int x)
 {
     return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);
 }
-// all-reduce over a 16-lane row; every lane gets the same bits
+// all-reduce over an env's 8 lanes (half a DPP row); every lane gets the same bits
 __device__ __forceinline__ float row_sum(float x)
 {
     x += dpp_f<0xB1>(x);   // quad_perm [1,0,3,2]
     x += dpp_f<0x4E>(x);   // quad_perm [2,3,0,1]
     x += dpp_f<0x141>(x);  // row_half_mirror
-    x += dpp_f<0x140>(x);  // row_mirror
     return x;
 }
 __device__ __forceinline__ int row_sum_i(int x)
@@ -53,7 +56,6 @@ __device__ __forceinline__ int row_sum_i(int x)
     x += dpp_i<0xB1>(x);
     x += dpp_i<0x4E>(x);
     x += dpp_i<0x141>(x);
-    x += dpp_i<0x140>(x);
     return x;
 }
 // value held by lane `src` (0..15) of this lane's row
@@ -168,14 +170,14 @@ __global__ __launch_bounds__(BLOCK) void fly_kernel(const FlyConfig* __restrict_
     const int n = c->num_envs;
     const int tid = threadIdx.x;
     const int sub = tid & (LANES_PER_ENV - 1);
-    const int env_in_blk = tid >> 4;
+    const int env_in_blk = tid / LANES_PER_ENV;
     const long e_raw = (long)blockIdx.x * ENVS_PER_BLOCK + env_in_blk;
     const bool valid = e_raw < n;
     const long e = valid ? e_raw : (long)(n - 1);   // tail lanes shadow the last env; stores are masked
     const bool is_leg = sub < FLY_NUM_LEGS;
-    const bool is_abd = (sub >= FLY_NUM_LEGS) && (sub < FLY_NUM_CONTACT);
+    const bool is_abd = sub < FLY_NUM_ABDOMEN;             // the first five lanes also own an abdomen point
     const int leg = is_leg ? sub : 0;
-    const int abd = is_abd ? sub - FLY_NUM_LEGS : 0;
+    const int abd = is_abd ? sub : 0;
     const int j0 = 3 * leg;
 
     // per-lane tables
@@ -207,7 +209,8 @@ __global__ __launch_bounds__(BLOCK) void fly_kernel(const FlyConfig* __restrict_
     if (NEED_FLAG) rs = (int)(b.reset[e] != 0);
     long progress = 0;
     if (NEED_PROG) progress = b.progress[e];
-    float cf[3] = {0, 0, 0};   // this lane's contact point force (leg tip or abdomen point)
+    float cf[3] = {0, 0, 0};   // this lane's leg-tip contact force (lanes 0..5)
+    float cfa[3] = {0, 0, 0};  // this lane's abdomen-point contact force (lanes 0..4)
 
     // ---- K1: targets -------------------------------------------------------------------------
     if (PH & PH_SCALE) {
@@ -223,10 +226,13 @@ __global__ __launch_bounds__(BLOCK) void fly_kernel(const FlyConfig* __restrict_
     }
     if (!(PH & (PH_INTEGRATE)) && (PH & (PH_OBS | PH_REWARD))) {
         // unfused packs read the contact forces the integrator left in HBM
-        if (is_leg || is_abd) {
-            const int k = is_leg ? (FLY_NUM_ABDOMEN + leg) : abd;
-            const float* fp = b.contact + (e * FLY_NUM_CONTACT + k) * 3;
+        if (is_leg) {
+            const float* fp = b.contact + (e * FLY_NUM_CONTACT + FLY_NUM_ABDOMEN + leg) * 3;
             cf[0] = fp[0]; cf[1] = fp[1]; cf[2] = fp[2];
+        }
+        if (is_abd) {
+            const float* fp = b.contact + (e * FLY_NUM_CONTACT + abd) * 3;
+            cfa[0] = fp[0]; cfa[1] = fp[1]; cfa[2] = fp[2];
         }
     }
 
@@ -265,7 +271,6 @@ __global__ __launch_bounds__(BLOCK) void fly_kernel(const FlyConfig* __restrict_
         const float azim = c->leg_azimuth[leg], sg = c->leg_sigma[leg];
         const float ab0 = c->abdomen_pts[abd][0], ab1 = c->abdomen_pts[abd][1], ab2 = c->abdomen_pts[abd][2];
         const float al0 = c->alpha0, be0 = c->beta0;
-        const bool contact_lane = is_leg || is_abd;
 
         for (int s = 0; s < nsub; ++s) {
             // 1. joints (leg lanes; the others integrate zeros)
@@ -299,32 +304,37 @@ __global__ __launch_bounds__(BLOCK) void fly_kernel(const FlyConfig* __restrict_
             float rho = fmaf(Lf, ca, Lt * cg), zeta = fmaf(Lf, sa, Lt * sgm);
             float rhod = -fmaf(Lf * sa, ald, Lt * sgm * gmd);
             float zetad = fmaf(Lf * ca, ald, Lt * cg * gmd);
-            float rbx = is_leg ? fmaf(cp, rho, att0) : ab0;
-            float rby = is_leg ? fmaf(sp, rho, att1) : ab1;
-            float rbz = is_leg ? att2 + zeta : ab2;
-            float rdx = is_leg ? fmaf(cp, rhod, -(sp * rho * psid)) : 0.0f;
-            float rdy = is_leg ? fmaf(sp, rhod, cp * rho * psid) : 0.0f;
-            float rdz = is_leg ? zetad : 0.0f;
-            float rwx = dot3(R00, R01, R02, rbx, rby, rbz);
-            float rwy = dot3(R10, R11, R12, rbx, rby, rbz);
-            float rwz = dot3(R20, R21, R22, rbx, rby, rbz);
-            float d = -(r.pz + rwz);
-            float ux = r.vx + fmaf(r.wy, rwz, -(r.wz * rwy)) + dot3(R00, R01, R02, rdx, rdy, rdz);
-            float uy = r.vy + fmaf(r.wz, rwx, -(r.wx * rwz)) + dot3(R10, R11, R12, rdx, rdy, rdz);
-            float uz = r.vz + fmaf(r.wx, rwy, -(r.wy * rwx)) + dot3(R20, R21, R22, rdx, rdy, rdz);
-            float fn = fmaxf(kc * d * fmaf(-cd, uz, 1.0f), 0.0f);
-            float ut = __builtin_amdgcn_sqrtf(fmaf(ux, ux, uy * uy));          // 1-ulp hardware sqrt / rcp
-            float ft = fminf(cv * ut, mu * fn);
-            float sc = ft * __builtin_amdgcn_rcpf(ut + 1e-9f);
-            const bool touch = contact_lane && (d > 0.0f);
-            float fx = touch ? -sc * ux : 0.0f;
-            float fy = touch ? -sc * uy : 0.0f;
-            float fz = touch ? fn : 0.0f;
-            cf[0] = fx; cf[1] = fy; cf[2] = fz;
-            float Fx = row_sum(fx), Fy = row_sum(fy), Fz = row_sum(fz);
-            float Tx = row_sum(fmaf(rwy, fz, -(rwz * fy)));
-            float Ty = row_sum(fmaf(rwz, fx, -(rwx * fz)));
-            float Tz = row_sum(fmaf(rwx, fy, -(rwy * fx)));
+            // one contact point: world offset, point velocity, penalty normal force, capped viscous
+            // friction; returns the force and accumulates its torque about the root
+            float Fx_l = 0.0f, Fy_l = 0.0f, Fz_l = 0.0f, Tx_l = 0.0f, Ty_l = 0.0f, Tz_l = 0.0f;
+            auto contact = [&](float rbx, float rby, float rbz, float rdx, float rdy, float rdz, bool lane_on, float (&f)[3]) {
+                float rwx = dot3(R00, R01, R02, rbx, rby, rbz);
+                float rwy = dot3(R10, R11, R12, rbx, rby, rbz);
+                float rwz = dot3(R20, R21, R22, rbx, rby, rbz);
+                float d = -(r.pz + rwz);
+                float ux = r.vx + fmaf(r.wy, rwz, -(r.wz * rwy)) + dot3(R00, R01, R02, rdx, rdy, rdz);
+                float uy = r.vy + fmaf(r.wz, rwx, -(r.wx * rwz)) + dot3(R10, R11, R12, rdx, rdy, rdz);
+                float uz = r.vz + fmaf(r.wx, rwy, -(r.wy * rwx)) + dot3(R20, R21, R22, rdx, rdy, rdz);
+                float fn = fmaxf(kc * d * fmaf(-cd, uz, 1.0f), 0.0f);
+                float ut = __builtin_amdgcn_sqrtf(fmaf(ux, ux, uy * uy));      // 1-ulp hardware sqrt / rcp
+                float ft = fminf(cv * ut, mu * fn);
+                float sc = ft * __builtin_amdgcn_rcpf(ut + 1e-9f);
+                const bool touch = lane_on && (d > 0.0f);
+                float fx = touch ? -sc * ux : 0.0f;
+                float fy = touch ? -sc * uy : 0.0f;
+                float fz = touch ? fn : 0.0f;
+                f[0] = fx; f[1] = fy; f[2] = fz;
+                Fx_l += fx; Fy_l += fy; Fz_l += fz;
+                Tx_l += fmaf(rwy, fz, -(rwz * fy));
+                Ty_l += fmaf(rwz, fx, -(rwx * fz));
+                Tz_l += fmaf(rwx, fy, -(rwy * fx));
+            };
+            // pass A: the leg tip (moving with the joints); pass B: the fixed abdomen point
+            contact(fmaf(cp, rho, att0), fmaf(sp, rho, att1), att2 + zeta,
+                    fmaf(cp, rhod, -(sp * rho * psid)), fmaf(sp, rhod, cp * rho * psid), zetad, is_leg, cf);
+            contact(ab0, ab1, ab2, 0.0f, 0.0f, 0.0f, is_abd, cfa);
+            float Fx = row_sum(Fx_l), Fy = row_sum(Fy_l), Fz = row_sum(Fz_l);
+            float Tx = row_sum(Tx_l), Ty = row_sum(Ty_l), Tz = row_sum(Tz_l);
             // 3. root, semi-implicit Euler (replicated over the row)
             r.vx = clampf(fmaf(h, Fx * minv, r.vx) * ld, vlim);
             r.vy = clampf(fmaf(h, Fy * minv, r.vy) * ld, vlim);
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(BLOCK) void fly_kernel(const FlyConfig* __restrict_
         RootObs ro = root_obs(c, r);
         pot = ro.pot;                                     // fly.py:787
         float* row = obs_tile + env_in_blk * FLY_NUM_OBS;
-        if (sub == 15) {
+        if (sub == LANES_PER_ENV - 1) {
             row[0] = r.pz; row[1] = ro.vl[0]; row[2] = ro.vl[1]; row[3] = ro.vl[2];
             row[4] = ro.wl[0]; row[5] = ro.wl[1]; row[6] = ro.wl[2];
             row[7] = ro.yaw; row[8] = ro.roll; row[9] = ro.ang; row[10] = ro.up_proj; row[11] = ro.heading_proj;
@@ -389,7 +399,7 @@ __global__ __launch_bounds__(BLOCK) void fly_kernel(const FlyConfig* __restrict_
             row[67 + leg] = touching_f;
         }
         __syncthreads();
-        // one contiguous 16 x 73 tile per workgroup, 16-byte stores
+        // one contiguous 32 x 73 tile per workgroup, 16-byte stores
         const long tile_base = (long)blockIdx.x * ENVS_PER_BLOCK * FLY_NUM_OBS;
         const long total = (long)n * FLY_NUM_OBS;
         const float4* src4 = reinterpret_cast<const float4*>(obs_tile);
@@ -435,10 +445,10 @@ __global__ __launch_bounds__(BLOCK) void fly_kernel(const FlyConfig* __restrict_
         elec = row_sum(elec); acost = row_sum(acost);
         lim = row_sum_i(lim); touching = row_sum_i(touching);
         // abdomen: per-body component sums added in body order (fly.py:756), bit-stable mask
-        float bsum = is_abd ? __fadd_rn(__fadd_rn(cf[0], cf[1]), cf[2]) : 0.0f;
+        float bsum = is_abd ? __fadd_rn(__fadd_rn(cfa[0], cfa[1]), cfa[2]) : 0.0f;
         float abd_sum = 0.0f;
 #pragma unroll
-        for (int k = 0; k < FLY_NUM_ABDOMEN; ++k) abd_sum = __fadd_rn(abd_sum, row_get(bsum, FLY_NUM_LEGS + k));
+        for (int k = 0; k < FLY_NUM_ABDOMEN; ++k) abd_sum = __fadd_rn(abd_sum, row_get(bsum, k));
         const float z = z_obs;
         float heading_r = (heading_proj > 0.8f) ? hw : __fmul_rn(hw, heading_proj) / 0.8f;
         float up_r = 0.0f;
@@ -483,20 +493,23 @@ __global__ __launch_bounds__(BLOCK) void fly_kernel(const FlyConfig* __restrict_
 #pragma unroll
             for (int i = 0; i < 3; ++i) { dp[2 * i] = jq[i]; dp[2 * i + 1] = jqd[i]; }
         }
-        if (sub == 15) {
+        if (sub == LANES_PER_ENV - 1) {
             float* rp = b.root + e * FLY_ROOT_DIM;
             rp[0] = r.px; rp[1] = r.py; rp[2] = r.pz; rp[3] = r.qx; rp[4] = r.qy; rp[5] = r.qz; rp[6] = r.qw;
             rp[7] = r.vx; rp[8] = r.vy; rp[9] = r.vz; rp[10] = r.wx; rp[11] = r.wy; rp[12] = r.wz;
         }
     }
     if (PH & PH_INTEGRATE) {
-        if (is_leg || is_abd) {
-            const int k = is_leg ? (FLY_NUM_ABDOMEN + leg) : abd;
-            float* fp = b.contact + (e * FLY_NUM_CONTACT + k) * 3;
+        if (is_leg) {
+            float* fp = b.contact + (e * FLY_NUM_CONTACT + FLY_NUM_ABDOMEN + leg) * 3;
             fp[0] = cf[0]; fp[1] = cf[1]; fp[2] = cf[2];
         }
+        if (is_abd) {
+            float* fp = b.contact + (e * FLY_NUM_CONTACT + abd) * 3;
+            fp[0] = cfa[0]; fp[1] = cfa[1]; fp[2] = cfa[2];
+        }
     }
-    if (sub == 14) {
+    if (sub == LANES_PER_ENV - 2) {
         if (PH & (PH_RESET | PH_OBS)) { b.pot[e] = pot; b.prev_pot[e] = prev_pot; }
         if (PH & (PH_RESET | PH_REWARD)) b.reset[e] = (int64_t)rs;
         if (PH & (PH_RESET | PH_REWARD | PH_PROGRESS)) b.progress[e] = (int64_t)progress;
