@@ -295,6 +295,16 @@ __device__ __forceinline__ void forward_body(
         // offsets from being hoisted out of the tile loop (they would all be live across it and spill)
         int tl = tid;
         asm volatile("" : "+v"(tl));
+        // the sampling noise of this tile's (row, column) slots of the last phase, requested now: one
+        // wave per SIMD (8192 rollout rows = one tile per CU) has nobody to hide a late HBM load behind
+        float eps_pre[BM * MLP_OUT / THREADS];
+        if (smp_eps) {
+#pragma unroll
+            for (int k = 0; k < BM * MLP_OUT / THREADS; ++k) {
+                const int i = tl + k * THREADS, row = i >> 5, col = i & 31;
+                eps_pre[k] = (col < MLP_NACT && row < nvalid) ? (smp_eps + row0 * MLP_NACT)[row * MLP_NACT + col] : 0.0f;
+            }
+        }
         if (STAMP) stamps = stamps_base + tile * 16;         // one 16-slot record per tile
         stamp<STAMP>(stamps, 0);
         if (STAMP && threadIdx.x == 0) {
@@ -381,7 +391,9 @@ __device__ __forceinline__ void forward_body(
                     make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
         }
         __syncthreads();
-        for (int i = tl; i < BM * MLP_OUT; i += THREADS) {
+#pragma unroll
+        for (int k = 0; k < BM * MLP_OUT / THREADS; ++k) {
+            const int i = tl + k * THREADS;
             const int row = i >> 5, col = i & 31;
             float z = ((ldsB[i] + ldsB[BM * MLP_OUT + i]) + ldsB[2 * BM * MLP_OUT + i]) + ldsB[3 * BM * MLP_OUT + i];
             z += ldsBias[LB4 + col];
@@ -400,7 +412,7 @@ __device__ __forceinline__ void forward_body(
                 const bool on = (col < MLP_NACT) && in;
                 if (on) {
                     const float L = ldsBias[LSD + col];
-                    a = y + L * (smp_eps + row0 * MLP_NACT)[row * MLP_NACT + col];
+                    a = y + L * eps_pre[k];
                     const float xj = (a - y) / L;
                     x2 = xj * xj;
                     lg = ldsBias[LLG + col];
