@@ -468,18 +468,14 @@ struct HFrag { float4 v[NT][4]; };
 template <int N, int NT>
 __device__ __forceinline__ void hfrag_load(HFrag<NT>& hf, const float* __restrict__ htile, int nvalid, int col0, int lane)
 {
-    const int r = lane & 31;
+    // rows past the end of the batch read the last valid row instead: their results are never
+    // stored and a row of an MFMA only feeds the same row, so no predicate and no zero fill
+    const int r = min(lane & 31, nvalid - 1);
+    const float* hrow = htile + r * N + col0 + acc_n(0, lane);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) hf.v[t][g] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < nvalid) {
-        const float* hrow = htile + r * N + col0 + acc_n(0, lane);
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) hf.v[t][g] = *reinterpret_cast<const float4*>(hrow + 32 * t + 8 * g);
-    }
+        for (int g = 0; g < 4; ++g) hf.v[t][g] = *reinterpret_cast<const float4*>(hrow + 32 * t + 8 * g);
 }
 
 // writes dZ to the gradient rows in HBM and (lds_out != nullptr) to the LDS tile the next GEMM reads
