@@ -18,7 +18,7 @@ extern "C" hipError_t flyhip_launch_td_gae(const float* reward, const float* v, 
 
 extern "C" hipError_t flyhip_launch_mlp_forward(const float* P, const float* PF, const float* x, int64_t n, float* mu_out,
                                                 float* v_out, float* out_save, float* h1_save, float* h2_save,
-                                                float* h3_save, void* stream);
+                                                float* h3_save, const uint16_t* PB, void* stream);
 
 extern "C" hipError_t flyhip_launch_mlp_backward_dx(const float* PT, const float* out_saved, const float* h1,
                                                     const float* h2, const float* h3, const float* action,
@@ -50,7 +50,8 @@ extern "C" hipError_t flyhip_launch_dqn_huber_td(const float* q_table, const flo
 extern "C" hipError_t flyhip_launch_mlp_forward_sample(const float* P, const float* PF, const float* x, int64_t n,
                                                        const float* eps, const float* var, int var_steps,
                                                        float var_decay, float var_min, float* act_out,
-                                                       float* logp_out, float* mu_out, float* v_out, void* stream);
+                                                       float* logp_out, float* mu_out, float* v_out, const uint16_t* PB,
+                                                       void* stream);
 
 extern "C" hipError_t flyhip_launch_mlp_fwd_bwd(const float* P, const float* PF, const float* PT, const float* x, int64_t n,
                                                 float* out_save, float* h1_save, float* h2_save, float* h3_save,
@@ -125,7 +126,7 @@ int launch(FlyHandle h, int phases, const float* actions, const FlyBuffers* b, v
 extern "C" {
 
 const char* fly_last_error(void) { return g_err; }
-int fly_abi_version(void) { return 3; }
+int fly_abi_version(void) { return 4; }
 
 int fly_create(const FlyConfig* cfg, FlyHandle* out)
 {
@@ -243,12 +244,14 @@ int ppo_step_bookkeeping(const float* reward, int64_t n, float* score_acc, float
 }
 
 int mlp_forward(const float* params, const float* params_frag, const float* x, int64_t n, float* mu_out, float* v_out,
-                float* out_save, float* h1_save, float* h2_save, float* h3_save, void* stream)
+                float* out_save, float* h1_save, float* h2_save, float* h3_save, const uint16_t* params_b3, void* stream)
 {
+    if (((uintptr_t)params_b3 & 15)) return fail(FLY_E_ARG, "mlp_forward: params_b3 must be 16-byte aligned");
     if (!params || !params_frag || !x) return fail(FLY_E_ARG, "mlp_forward: null params/x");
     if (n <= 0) return fail(FLY_E_ARG, "mlp_forward: n must be > 0");
     if (((uintptr_t)params_frag & 15)) return fail(FLY_E_ARG, "mlp_forward: params_frag must be 16-byte aligned");
-    hipError_t e = flyhip_launch_mlp_forward(params, params_frag, x, n, mu_out, v_out, out_save, h1_save, h2_save, h3_save, stream);
+    hipError_t e = flyhip_launch_mlp_forward(params, params_frag, x, n, mu_out, v_out, out_save, h1_save, h2_save, h3_save,
+                                             params_b3, stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_forward launch");
     return FLY_OK;
 }
@@ -256,14 +259,14 @@ int mlp_forward(const float* params, const float* params_frag, const float* x, i
 int mlp_forward_sample(const float* params, const float* params_frag, const float* x, int64_t n,
                        const float* eps, const float* var, int32_t var_steps, float var_decay,
                        float var_min, float* act_out, float* logp_out, float* mu_out, float* v_out,
-                       void* stream)
+                       const uint16_t* params_b3, void* stream)
 {
     if (!params || !params_frag || !x || !eps || !var || !act_out || !logp_out)
         return fail(FLY_E_ARG, "mlp_forward_sample: null pointer");
     if (n <= 0) return fail(FLY_E_ARG, "mlp_forward_sample: n must be > 0");
     if (var_steps < 0 || var_steps > (1 << 20)) return fail(FLY_E_ARG, "mlp_forward_sample: var_steps out of range");
     hipError_t e = flyhip_launch_mlp_forward_sample(params, params_frag, x, n, eps, var, var_steps, var_decay, var_min, act_out, logp_out,
-                                                    mu_out, v_out, stream);
+                                                    mu_out, v_out, params_b3, stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_forward_sample launch");
     return FLY_OK;
 }

@@ -63,4 +63,25 @@
 #define MLP_OFF_TF4 (MLP_OFF_TF3 + MLP_H2 * MLP_H3)        /* 49152: W4^T 128 outputs, 32 reduced */
 #define MLP_FRAG_T_FLOATS (MLP_OFF_TF4 + MLP_H3 * MLP_OUT) /* 53248 */
 
+
+/* bf16x3 operand planes (v_mfma_f32_32x32x16_bf16): every fp32 weight w is also kept as three bf16
+ * terms w = w0 + w1 + w2 (w0 = bf16(w), w1 = bf16(w - w0), w2 = bf16(w - w0 - w1); the sum is exact)
+ * in the order the 32x32x16 MFMA consumes them: element (n, k) of an operand with N outputs and K
+ * reduced, term p, lives at (16-bit units)
+ *     (((n/32) * (K/16) + k/16) * 3 + p) * 512 + (((k%16)/8) * 32 + n%32) * 8 + k%8
+ * i.e. [column tile][16-wide k block][term][lane][8]: one wave-load = one contiguous KiB.
+ * PB  forward operands  W1 [256][80] | W2 as two K = 128 operands (k < 128, k >= 128) | W3 | W4
+ * PTB backward operands W2^T [256][128] | W3^T [128][128] | W4^T [128][32]
+ * tools/bf16x3_gemm.hip: six product terms (w0x0 in one accumulator, w0x1 w1x0 w1x1 w0x2 w2x0 in a
+ * second, summed at the end) are MORE accurate than v_mfma_f32_32x32x2_f32 on the same data. */
+#define MLP_OFF_PB1 0
+#define MLP_OFF_PB2 (MLP_OFF_PB1 + 3 * MLP_H1 * MLP_IN_PAD)   /*  61440 */
+#define MLP_OFF_PB3 (MLP_OFF_PB2 + 3 * MLP_H2 * MLP_H1)       /* 159744 */
+#define MLP_OFF_PB4 (MLP_OFF_PB3 + 3 * MLP_H3 * MLP_H2)       /* 208896 */
+#define MLP_PB_HALVES (MLP_OFF_PB4 + 3 * MLP_OUT * MLP_H3)    /* 221184 16-bit words */
+#define MLP_OFF_PTB2 0
+#define MLP_OFF_PTB3 (MLP_OFF_PTB2 + 3 * MLP_H1 * MLP_H2)     /*  98304 */
+#define MLP_OFF_PTB4 (MLP_OFF_PTB3 + 3 * MLP_H2 * MLP_H3)     /* 147456 */
+#define MLP_PTB_HALVES (MLP_OFF_PTB4 + 3 * MLP_H3 * MLP_OUT)  /* 159744 16-bit words */
+
 #endif

@@ -138,6 +138,130 @@ __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8
 // store, and -- when `gdst` is given -- the same 16 bytes to the saved-activation rows in HBM.  A
 // wave's four stores of one column tile touch the same 32 lines (one 128-byte line per row) and
 // together fill them, so L2 merges them into full-line writes; no LDS read-back pass is needed.
+// ---------------------------------------------------------------------------------------------
+// bf16x3 GEMM path: the same tile GEMMs on v_mfma_f32_32x32x16_bf16 with both operands split into
+// three bf16 terms (mlp_layout.h).  Six MFMAs of 8 passes per 16-wide k block replace eight fp32
+// MFMAs of 16 passes: 192 instead of 512 matrix cycles, and (tools/bf16x3_gemm.hip) a smaller
+// error than the fp32 MFMA chain because each instruction sums its 16 products before rounding.
+// The large term w0*x0 accumulates in `hi`, the five small ones in `lo`; the epilogue adds them.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+struct Frag3 { float4 p[3]; };                                   // one operand fragment: 3 terms x 8 bf16
+__device__ __forceinline__ bf16x8 as_bf16x8(const float4& v) { return __builtin_bit_cast(bf16x8, v); }
+
+constexpr int B3_PAD = 8;                                        // LDS row pitch (K + 8) bf16 = 4 banks past a multiple of 64
+constexpr int B3_RING = 4, B3_HEAD = 2, B3_ARING = 2;
+template <int K> constexpr int b3_plane() { return BM * (K + B3_PAD); }   // 16-bit words per term plane of a [32][K] tile
+
+struct WeightHead3 { Frag3 b[B3_HEAD]; };
+
+template <int K>
+__device__ __forceinline__ void gemm_prefetch_b3(WeightHead3& w, const u16* __restrict__ Wb, int tile0, int lane)
+{
+    static_assert(K / 16 >= B3_HEAD, "at least B3_HEAD k blocks");
+    const u16* bp = Wb + (long)tile0 * (K / 16) * 1536 + lane * 8;
+#pragma unroll
+    for (int s = 0; s < B3_HEAD; ++s)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) w.b[s].p[p] = *reinterpret_cast<const float4*>(bp + s * 1536 + p * 512);
+}
+
+// (hi, lo) (+)= W[col tile][K] * A[32 rows x K]^T; lds_in = term 0 plane of the activation tile
+// ([32][K + 8] bf16 per plane, planes b3_plane<K>() apart); Wb = this operand's planes.
+template <int K, bool ZERO = true>
+__device__ __forceinline__ void tile_gemm_b3(const WeightHead3& head, const u16* __restrict__ Wb, int tile0,
+                                             const u16* lds_in, f32x16& hi, f32x16& lo, int lane)
+{
+    constexpr int K16 = K / 16;
+    constexpr int RING = K16 < B3_RING ? K16 : B3_RING;
+    constexpr int ARING = K16 < B3_ARING ? K16 : B3_ARING;
+    const int r = lane & 31, h = lane >> 5;
+    const u16* ap = lds_in + r * (K + B3_PAD) + 8 * h;
+    const u16* bp = Wb + (long)tile0 * K16 * 1536 + lane * 8;
+    Frag3 b[RING], a[ARING];
+#pragma unroll
+    for (int s = 0; s < RING; ++s) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            if (s < ARING) a[s].p[p] = *reinterpret_cast<const float4*>(ap + p * b3_plane<K>() + 16 * s);
+            b[s].p[p] = s < B3_HEAD ? head.b[s].p[p] : *reinterpret_cast<const float4*>(bp + s * 1536 + p * 512);
+        }
+    }
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < K16; ++kb) {
+        const int s = kb % RING, sa = kb % ARING;
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 w0 = as_bf16x8(b[s].p[0]), w1 = as_bf16x8(b[s].p[1]), w2 = as_bf16x8(b[s].p[2]);
+        const bf16x8 x0 = as_bf16x8(a[sa].p[0]), x1 = as_bf16x8(a[sa].p[1]), x2 = as_bf16x8(a[sa].p[2]);
+        lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x2, (ZERO && kb == 0) ? z : lo, 0, 0, 0);
+        hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x0, (ZERO && kb == 0) ? z : hi, 0, 0, 0);
+        lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x0, lo, 0, 0, 0);
+        lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x1, lo, 0, 0, 0);
+        lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, x1, lo, 0, 0, 0);
+        lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x0, lo, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb + RING < K16) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b[s].p[p] = *reinterpret_cast<const float4*>(bp + (kb + RING) * 1536 + p * 512);
+        }
+        if (kb + ARING < K16) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) a[sa].p[p] = *reinterpret_cast<const float4*>(ap + p * b3_plane<K>() + 16 * (kb + ARING));
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// x = a + b + c exactly, each a bf16 (round to nearest even): the terms of the split
+__device__ __forceinline__ void split3(float x, u16& a, u16& b, u16& c)
+{
+    const __bf16 t0 = (__bf16)x;
+    const float r1 = x - (float)t0;
+    const __bf16 t1 = (__bf16)r1;
+    const float r2 = r1 - (float)t1;
+    const __bf16 t2 = (__bf16)r2;
+    a = __builtin_bit_cast(u16, t0); b = __builtin_bit_cast(u16, t1); c = __builtin_bit_cast(u16, t2);
+}
+
+// four consecutive columns of one row -> the three term planes of an LDS tile (8-byte stores)
+template <int K>
+__device__ __forceinline__ void store_split4(u16* lds_plane0, int row, int col, const float4& y)
+{
+    u16 a[4], b[4], c[4];
+    split3(y.x, a[0], b[0], c[0]); split3(y.y, a[1], b[1], c[1]);
+    split3(y.z, a[2], b[2], c[2]); split3(y.w, a[3], b[3], c[3]);
+    u16* q = lds_plane0 + row * (K + B3_PAD) + col;
+    *reinterpret_cast<uint2*>(q) = make_uint2(a[0] | ((unsigned)a[1] << 16), a[2] | ((unsigned)a[3] << 16));
+    *reinterpret_cast<uint2*>(q + b3_plane<K>()) = make_uint2(b[0] | ((unsigned)b[1] << 16), b[2] | ((unsigned)b[3] << 16));
+    *reinterpret_cast<uint2*>(q + 2 * b3_plane<K>()) = make_uint2(c[0] | ((unsigned)c[1] << 16), c[2] | ((unsigned)c[3] << 16));
+}
+
+// bias + ELU epilogue of the bf16x3 path: hi + lo, activation to HBM as fp32 (the backward and dW
+// read it) and to the LDS tile of the next GEMM as three bf16 terms.  N = width of the LDS tile.
+template <int N, int NG = N>
+__device__ __forceinline__ void epilogue_elu_b3(const f32x16& hi, const f32x16& lo, const float* __restrict__ bias, int col0,
+                                                u16* lds_plane0, int lane, float* __restrict__ gtile, int nvalid)
+{
+    const int r = lane & 31;
+    float4 y[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int nb = col0 + acc_n(g, lane);
+        const float4 bv = *reinterpret_cast<const float4*>(bias + nb);
+        y[g].x = elu((hi[4 * g + 0] + lo[4 * g + 0]) + bv.x);
+        y[g].y = elu((hi[4 * g + 1] + lo[4 * g + 1]) + bv.y);
+        y[g].z = elu((hi[4 * g + 2] + lo[4 * g + 2]) + bv.z);
+        y[g].w = elu((hi[4 * g + 3] + lo[4 * g + 3]) + bv.w);
+        store_split4<N>(lds_plane0, r, nb, y[g]);
+    }
+    if (gtile != nullptr && r < nvalid) {
+        float* grow = gtile + r * NG + col0 + acc_n(0, lane);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(grow + 8 * g) = y[g];
+    }
+}
+
 // `gtile` points at this tile's first row of the destination (a wave-uniform pointer); lanes
 // address it with small 32-bit offsets, and all stores sit under ONE predicate (`nvalid` rows of
 // the tile exist): 64-bit per-lane address arithmetic and per-store exec masking are issue slots
@@ -433,6 +557,247 @@ __device__ __forceinline__ void forward_body(
     }
 }
 
+// bf16x3 variant of the forward body: same tile flow, activations live in LDS as three bf16 term planes
+constexpr int B3_TILE_FLOATS = 3 * b3_plane<MLP_H2>() / 2;        // a [32][128] tile as three planes, in floats
+constexpr int FWD_B3_LDS_FLOATS = 2 * B3_TILE_FLOATS + LDS_C_FLOATS;
+
+// The body walks tiles first_tile, first_tile + tile_stride, ... (< ntiles) on the caller's LDS
+// arena.
+template <bool STAMP>
+__device__ __forceinline__ void forward_body_b3(
+    float* lds, const long first_tile, const long tile_stride,
+    const float* __restrict__ P, const u16* __restrict__ PB, const float* __restrict__ x, long n,
+    float* __restrict__ mu_out, float* __restrict__ v_out, float* __restrict__ out_save,
+    float* __restrict__ h1_save, float* __restrict__ h2_save, float* __restrict__ h3_save,
+    const float* __restrict__ smp_eps, const float* __restrict__ smp_var, float* __restrict__ smp_act,
+    float* __restrict__ smp_logp, unsigned long long* __restrict__ stamps_base,
+    const int smp_var_steps = 0, const float smp_var_decay = 0.0f, const float smp_var_min = 0.0f)
+{
+    unsigned long long* stamps = stamps_base;
+    u16* ldsA = reinterpret_cast<u16*>(lds);                                   // H1 half / H3: three [32][136] planes
+    u16* ldsB = reinterpret_cast<u16*>(lds + B3_TILE_FLOATS);                  // X ([32][88] planes) / H2 / fp32 split-K partials
+    float* ldsBf = lds + B3_TILE_FLOATS;
+    float* ldsBias = lds + 2 * B3_TILE_FLOATS;   // b1 | b2 | b3 | b4 | sqrt(var) | log sqrt(var): read by every epilogue
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR: weight bases become scalar
+    const long ntiles = (n + BM - 1) / BM;
+    const long total = n * MLP_IN;
+
+    float4 xr[XV];
+    auto x_load = [&](long tile) {
+        const long base = tile * (BM * MLP_IN);
+#pragma unroll
+        for (int u = 0; u < XV; ++u) {
+            const long f = base + 4L * (tid + u * THREADS);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tid + u * THREADS < BM * MLP_IN / 4) {
+                if (f + 3 < total) v = *reinterpret_cast<const float4*>(x + f);
+                else {
+                    if (f < total) v.x = x[f];
+                    if (f + 1 < total) v.y = x[f + 1];
+                    if (f + 2 < total) v.z = x[f + 2];
+                }
+            }
+            xr[u] = v;
+        }
+    };
+    auto x_store = [&](int tid) {   // registers -> ldsB as three [32][80+8] bf16 term planes; pad columns 73..79 zeroed
+#pragma unroll
+        for (int u = 0; u < XV; ++u) {
+            const int i4 = tid + u * THREADS;
+            if (i4 < BM * MLP_IN / 4) {
+                const float e[4] = {xr[u].x, xr[u].y, xr[u].z, xr[u].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int f = 4 * i4 + j;
+                    const int rr = f / MLP_IN, cc = f - rr * MLP_IN;
+                    u16 sa, sb, sc;
+                    split3(e[j], sa, sb, sc);
+                    u16* q = ldsB + rr * (MLP_IN_PAD + B3_PAD) + cc;
+                    q[0] = sa; q[b3_plane<MLP_IN_PAD>()] = sb; q[2 * b3_plane<MLP_IN_PAD>()] = sc;
+                }
+            }
+        }
+        if (tid < BM * (MLP_IN_PAD - MLP_IN)) {
+            const int rr = tid / (MLP_IN_PAD - MLP_IN), cc = MLP_IN + tid - rr * (MLP_IN_PAD - MLP_IN);
+            u16* q = ldsB + rr * (MLP_IN_PAD + B3_PAD) + cc;
+            q[0] = 0; q[b3_plane<MLP_IN_PAD>()] = 0; q[2 * b3_plane<MLP_IN_PAD>()] = 0;
+        }
+    };
+
+    long tile = first_tile;
+    if (tile < ntiles) x_load(tile);
+    {   // biases (and the sampling constants) -> LDS once per workgroup; the first tile's barrier publishes them
+        ldsBias[LB1 + tid] = P[MLP_OFF_B1 + tid];
+        if (tid < MLP_H2) ldsBias[LB2 + tid] = P[MLP_OFF_B2 + tid];
+        else ldsBias[LB3 + tid - MLP_H2] = P[MLP_OFF_B3 + tid - MLP_H2];
+        if (tid < MLP_OUT) ldsBias[LB4 + tid] = P[MLP_OFF_B4 + tid];
+        if (smp_var && tid >= 64 && tid < 64 + MLP_NACT) {
+            float v = smp_var[tid - 64];
+            for (int i = 0; i < smp_var_steps; ++i) v = fmaxf(smp_var_min, v - smp_var_decay);   // ppo.py:236-237, not yet applied to the tensor
+            const float L = sqrtf(v);
+            ldsBias[LSD + tid - 64] = L;
+            ldsBias[LLG + tid - 64] = logf(L);
+        }
+    }
+    for (; tile < ntiles; tile += tile_stride) {
+        const long row0 = tile * BM;
+        const int nvalid = (int)(n - row0 < BM ? n - row0 : BM);            // rows of this tile that exist
+        float* h1_tile = h1_save ? h1_save + row0 * MLP_H1 : nullptr;       // wave-uniform tile bases
+        float* h2_tile = h2_save ? h2_save + row0 * MLP_H2 : nullptr;
+        float* h3_tile = h3_save ? h3_save + row0 * MLP_H3 : nullptr;
+        // opaque per-iteration copy of the thread index: keeps the dozens of tile-invariant LDS/global
+        // offsets from being hoisted out of the tile loop (they would all be live across it and spill)
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
+        // the sampling noise of this tile's (row, column) slots of the last phase, requested now: one
+        // wave per SIMD (8192 rollout rows = one tile per CU) has nobody to hide a late HBM load behind
+        float eps_pre[BM * MLP_OUT / THREADS];
+        if (smp_eps) {
+#pragma unroll
+            for (int k = 0; k < BM * MLP_OUT / THREADS; ++k) {
+                const int i = tl + k * THREADS, row = i >> 5, col = i & 31;
+                eps_pre[k] = (col < MLP_NACT && row < nvalid) ? (smp_eps + row0 * MLP_NACT)[row * MLP_NACT + col] : 0.0f;
+            }
+        }
+        if (STAMP) stamps = stamps_base + tile * 16;         // one 16-slot record per tile
+        stamp<STAMP>(stamps, 0);
+        if (STAMP && threadIdx.x == 0) {
+            unsigned long long t;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+            // top 16 bits: which CU this workgroup landed on (HW_ID cu/sh/se bits 8..15, XCC_ID)
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+            t = (t & 0xffffffffffffull) | ((unsigned long long)(((hw >> 8) & 0xff) | ((xcc & 0xf) << 8)) << 48);
+            stamps[14] = t;
+        }
+        // Layers 1 and 2 run in two halves of 128 hidden-1 columns so that only a [32][128] slice of
+        // H1 is ever in LDS: L1 produces columns
+        // [0,128), L2 accumulates their k range, L1 produces [128,256), L2 accumulates the rest.
+        WeightHead3 w1a, w1b, w2a, w2b, w3;
+        gemm_prefetch_b3<MLP_IN_PAD>(w1a, PB + MLP_OFF_PB1, wave, lane);       // lands during the x staging
+        x_store(tl);
+        __syncthreads();
+        if (tile + tile_stride < ntiles) x_load(tile + tile_stride);     // lands during this tile's MFMAs
+        stamp<STAMP>(stamps, 1);
+        f32x16 hi2, lo2;
+        {   // L1, columns [0,128): wave owns 32 of them
+            f32x16 hi, lo;
+            tile_gemm_b3<MLP_IN_PAD>(w1a, PB + MLP_OFF_PB1, wave, ldsB, hi, lo, lane);
+            stamp<STAMP>(stamps, 2);
+            gemm_prefetch_b3<MLP_H2>(w2a, PB + MLP_OFF_PB2, wave, lane);              // both land during the epilogue
+            gemm_prefetch_b3<MLP_IN_PAD>(w1b, PB + MLP_OFF_PB1, 4 + wave, lane);
+            epilogue_elu_b3<MLP_H2, MLP_H1>(hi, lo, ldsBias + LB1, wave * 32, ldsA, lane, h1_tile, nvalid);
+        }
+        stamp<STAMP>(stamps, 3);
+        __syncthreads();
+        stamp<STAMP>(stamps, 4);
+        {   // L2 over k in [0,128), then L1 columns [128,256) -- one uninterrupted run of MFMAs
+            f32x16 hi, lo;
+            tile_gemm_b3<MLP_H2>(w2a, PB + MLP_OFF_PB2, wave, ldsA, hi2, lo2, lane);
+            tile_gemm_b3<MLP_IN_PAD>(w1b, PB + MLP_OFF_PB1, 4 + wave, ldsB, hi, lo, lane);
+            stamp<STAMP>(stamps, 5);
+            gemm_prefetch_b3<MLP_H2>(w2b, PB + MLP_OFF_PB2 + 3 * MLP_H2 * (MLP_H1 / 2), wave, lane);
+            __syncthreads();                                   // every wave has finished reading the first half of H1
+            epilogue_elu_b3<MLP_H2, MLP_H1>(hi, lo, ldsBias + LB1 + MLP_H1 / 2, wave * 32, ldsA, lane, h1_tile ? h1_tile + MLP_H1 / 2 : nullptr, nvalid);
+        }
+        stamp<STAMP>(stamps, 6);
+        __syncthreads();
+        stamp<STAMP>(stamps, 7);
+        {   // L2 over k in [128,256): 256 -> 128 complete, wave owns 32 columns
+            tile_gemm_b3<MLP_H2, false>(w2b, PB + MLP_OFF_PB2 + 3 * MLP_H2 * (MLP_H1 / 2), wave, ldsA, hi2, lo2, lane);
+            stamp<STAMP>(stamps, 8);
+            gemm_prefetch_b3<MLP_H2>(w3, PB + MLP_OFF_PB3, wave, lane);
+            epilogue_elu_b3<MLP_H2>(hi2, lo2, ldsBias + LB2, wave * 32, ldsB, lane, h2_tile, nvalid);   // x is dead: every wave passed the barrier above
+        }
+        __syncthreads();
+        Frag3 w4[2];                                                             // layer-4 weights of this wave's two k blocks
+        {   // L3: 128 -> 128 (actor | critic heads stacked)
+            f32x16 hi, lo;
+            stamp<STAMP>(stamps, 9);
+            tile_gemm_b3<MLP_H2>(w3, PB + MLP_OFF_PB3, wave, ldsB, hi, lo, lane);
+            stamp<STAMP>(stamps, 10);
+            const u16* bp = PB + MLP_OFF_PB4 + (wave * 2) * 1536 + lane * 8;    // [k block][term][lane][8]
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) w4[kk].p[pl] = *reinterpret_cast<const float4*>(bp + kk * 1536 + pl * 512);
+            epilogue_elu_b3<MLP_H3>(hi, lo, ldsBias + LB3, wave * 32, ldsA, lane, h3_tile, nvalid);
+        }
+        stamp<STAMP>(stamps, 11);
+        __syncthreads();
+        stamp<STAMP>(stamps, 12);
+        {   // L4: 128 -> 32, split-K over the four waves (32 k each), partials reduced through LDS
+            f32x16 hi, lo;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { hi[i] = 0.0f; lo[i] = 0.0f; }
+            const int r = lane & 31, h = lane >> 5;
+            const u16* ap = ldsA + r * (MLP_H3 + B3_PAD) + wave * 32 + 8 * h;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 xq[3], wq[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    xq[pl] = as_bf16x8(*reinterpret_cast<const float4*>(ap + pl * b3_plane<MLP_H3>() + 16 * kk));
+                    wq[pl] = as_bf16x8(w4[kk].p[pl]);
+                }
+                lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[0], xq[2], lo, 0, 0, 0);
+                hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[0], xq[0], hi, 0, 0, 0);
+                lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[2], xq[0], lo, 0, 0, 0);
+                lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[1], xq[1], lo, 0, 0, 0);
+                lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[0], xq[1], lo, 0, 0, 0);
+                lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[1], xq[0], lo, 0, 0, 0);
+            }
+            // every wave must be done reading H2 (ldsB, layer 3) before the partials overwrite it:
+            // they are -- the barrier after the layer-3 epilogue is behind all of them
+            float* part = ldsBf + wave * (BM * MLP_OUT);                         // [row][32]
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(part + r * MLP_OUT + acc_n(g, lane)) =
+                    make_float4(hi[4 * g] + lo[4 * g], hi[4 * g + 1] + lo[4 * g + 1], hi[4 * g + 2] + lo[4 * g + 2],
+                                hi[4 * g + 3] + lo[4 * g + 3]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < BM * MLP_OUT / THREADS; ++k) {
+            const int i = tl + k * THREADS;
+            const int row = i >> 5, col = i & 31;
+            float z = ((ldsBf[i] + ldsBf[BM * MLP_OUT + i]) + ldsBf[2 * BM * MLP_OUT + i]) + ldsBf[3 * BM * MLP_OUT + i];
+            z += ldsBias[LB4 + col];
+            float y = (col < MLP_NACT) ? elu(z) : ((col == MLP_NACT) ? z : 0.0f);   // ELU on the mean (ppo.py:30), none on v
+            const bool in = row < nvalid;
+            if (in) {
+                if (out_save) (out_save + row0 * MLP_OUT)[i] = y;
+                if (mu_out && col < MLP_NACT) (mu_out + row0 * MLP_NACT)[row * MLP_NACT + col] = y;
+                if (v_out && col == MLP_NACT) (v_out + row0)[row] = y;
+            }
+            if (smp_eps) {
+                // ppo.py:215-220 fused: the 32 lanes that hold one output row sample its action
+                // (a = mu + sqrt(var) eps), reduce the Mahalanobis term and sum log L with a fixed
+                // xor-butterfly over the half-wave, and write the clipped action and the log-prob.
+                float x2 = 0.0f, lg = 0.0f, a = 0.0f;
+                const bool on = (col < MLP_NACT) && in;
+                if (on) {
+                    const float L = ldsBias[LSD + col];
+                    a = y + L * eps_pre[k];
+                    const float xj = (a - y) / L;
+                    x2 = xj * xj;
+                    lg = ldsBias[LLG + col];
+                }
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) { x2 += __shfl_xor(x2, o, 32); lg += __shfl_xor(lg, o, 32); }
+                if (on) (smp_act + row0 * MLP_NACT)[row * MLP_NACT + col] = fminf(fmaxf(a, -1.0f), 1.0f);
+                if (col == 0 && in) (smp_logp + row0)[row] = -0.5f * (33.08178959434617f + x2) - lg;
+            }
+        }
+        stamp<STAMP>(stamps, 13);
+        if (STAMP && threadIdx.x == 0) {
+            unsigned long long t;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+            stamps[15] = t;
+        }
+        __syncthreads();            // ldsB (partials) is the next tile's input buffer
+    }
+}
+
 template <bool STAMP>
 __global__ __launch_bounds__(THREADS, 2) void mlp_forward_kernel(
     const float* __restrict__ P, const float* __restrict__ PF, const float* __restrict__ x, long n,
@@ -446,6 +811,18 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_forward_kernel(
     forward_body<STAMP>(lds, blockIdx.x, gridDim.x, P, PF, x, n, mu_out, v_out, out_save, h1_save,
                         h2_save, h3_save, smp_eps, smp_var, smp_act, smp_logp, stamps_base, smp_var_steps, smp_var_decay,
                         smp_var_min);
+}
+
+__global__ __launch_bounds__(THREADS, 2) void mlp_forward_b3_kernel(
+    const float* __restrict__ P, const u16* __restrict__ PB, const float* __restrict__ x, long n,
+    float* __restrict__ mu_out, float* __restrict__ v_out, float* __restrict__ out_save,
+    float* __restrict__ h1_save, float* __restrict__ h2_save, float* __restrict__ h3_save,
+    const float* __restrict__ smp_eps, const float* __restrict__ smp_var, float* __restrict__ smp_act,
+    float* __restrict__ smp_logp, int smp_var_steps, float smp_var_decay, float smp_var_min)
+{
+    __shared__ __attribute__((aligned(16))) float lds[FWD_B3_LDS_FLOATS];
+    forward_body_b3<false>(lds, blockIdx.x, gridDim.x, P, PB, x, n, mu_out, v_out, out_save, h1_save, h2_save, h3_save,
+                           smp_eps, smp_var, smp_act, smp_logp, nullptr, smp_var_steps, smp_var_decay, smp_var_min);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1092,8 +1469,16 @@ __global__ __launch_bounds__(ADAM_THREADS) void mlp_adam_apply_kernel(float* __r
 
 extern "C" hipError_t flyhip_launch_mlp_forward(const float* P, const float* PF, const float* x, int64_t n, float* mu_out,
                                                 float* v_out, float* out_save, float* h1_save, float* h2_save,
-                                                float* h3_save, void* stream)
+                                                float* h3_save, const uint16_t* PB, void* stream)
 {
+    if (PB) {       // bf16x3 GEMMs
+        const long tiles = (n + BM - 1) / BM;
+        const int grid = (int)(tiles <= 4 * 512 ? tiles : 512);
+        hipLaunchKernelGGL(mlp_forward_b3_kernel, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PB, x, (long)n, mu_out,
+                           v_out, out_save, h1_save, h2_save, h3_save, (const float*)nullptr, (const float*)nullptr,
+                           (float*)nullptr, (float*)nullptr, 0, 0.0f, 0.0f);
+        return hipGetLastError();
+    }
     // Large inputs (the critic pass over the whole rollout) run persistent workgroups, 3 per CU, each
     // walking many tiles with the next tile's rows prefetched.  Up to a few tiles per slot the
     // hardware's dynamic workgroup dispatch balances better than a fixed walk (1280 tiles over 768
@@ -1109,8 +1494,17 @@ extern "C" hipError_t flyhip_launch_mlp_forward(const float* P, const float* PF,
 extern "C" hipError_t flyhip_launch_mlp_forward_sample(const float* P, const float* PF, const float* x, int64_t n,
                                                        const float* eps, const float* var, int var_steps,
                                                        float var_decay, float var_min, float* act_out,
-                                                       float* logp_out, float* mu_out, float* v_out, void* stream)
+                                                       float* logp_out, float* mu_out, float* v_out, const uint16_t* PB,
+                                                       void* stream)
 {
+    if (PB) {
+        const long tiles = (n + BM - 1) / BM;
+        const int grid = (int)(tiles <= 4 * 512 ? tiles : 512);
+        hipLaunchKernelGGL(mlp_forward_b3_kernel, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PB, x, (long)n, mu_out,
+                           v_out, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, eps, var, act_out,
+                           logp_out, var_steps, var_decay, var_min);
+        return hipGetLastError();
+    }
     const long tiles = (n + BM - 1) / BM;
     const int grid = (int)(tiles <= 4 * PERSIST_GRID ? tiles : PERSIST_GRID);
     hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PF, x, (long)n,

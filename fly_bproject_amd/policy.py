@@ -65,6 +65,49 @@ def build_index_maps():
     return idx_f, idx_t
 
 
+def _plane_index(n, k, K):
+    """Position (16-bit words) of term 0 of element (n, k) of a bf16x3 operand with K reduced
+    (csrc/mlp_layout.h); terms 1 and 2 follow 512 and 1024 words later."""
+    return (((n // 32) * (K // 16) + k // 16) * 3) * 512 + (((k % 16) // 8) * 32 + n % 32) * 8 + k % 8
+
+
+PB_HALVES, PTB_HALVES = 221184, 159744
+OFF_PB = (0, 61440, 159744, 208896)
+OFF_PTB = (None, 0, 98304, 147456)
+
+
+def build_plane_maps():
+    """int32 [PACKED] maps master index -> term-0 position in PB / PTB (-1: no copy)."""
+    import numpy as np
+    idx_fb = np.full(PACKED, -1, np.int32)
+    idx_tb = np.full(PACKED, -1, np.int32)
+    layers = [(OFF_W1, H1, IN_PAD), (OFF_W2, H2, H1), (OFF_W3, H3, H2), (OFF_W4, OUT, H3)]
+    for li, (off_w, N, K) in enumerate(layers):
+        n, k = np.meshgrid(np.arange(N), np.arange(K), indexing="ij")
+        src = off_w + n * K + k
+        if li == 1:     # two K = 128 operands
+            idx_fb[src] = OFF_PB[li] + (k // 128) * (3 * N * 128) + _plane_index(n, k % 128, 128)
+        else:
+            idx_fb[src] = OFF_PB[li] + _plane_index(n, k, K)
+        if OFF_PTB[li] is not None:     # W^T: K outputs, N reduced
+            idx_tb[src] = OFF_PTB[li] + _plane_index(k, n, N)
+    for idx, size in ((idx_fb, PB_HALVES), (idx_tb, PTB_HALVES)):
+        used = idx[idx >= 0].astype(np.int64)
+        allpos = np.concatenate([used, used + 512, used + 1024])
+        assert len(np.unique(allpos)) == len(allpos) and allpos.max() < size
+    assert 3 * (idx_fb >= 0).sum() == PB_HALVES and 3 * (idx_tb >= 0).sum() == PTB_HALVES
+    return idx_fb, idx_tb
+
+
+def split_bf16x3(w):
+    """fp32 tensor -> three int16 tensors holding the bf16 terms w0 + w1 + w2 == w (exact)."""
+    w0 = w.to(torch.bfloat16)
+    r1 = w - w0.float()
+    w1 = r1.to(torch.bfloat16)
+    w2 = (r1 - w1.float()).to(torch.bfloat16)
+    return [t.view(torch.int16) for t in (w0, w1, w2)]
+
+
 class PackedPolicy:
     def __init__(self, net, device):
         self.device = torch.device(device)
@@ -72,6 +115,19 @@ class PackedPolicy:
         self.P = torch.zeros(PACKED, dtype=torch.float32, device=self.device)
         self.PF = torch.zeros(FRAG, dtype=torch.float32, device=self.device)      # forward operands, fragment order
         self.PT = torch.zeros(FRAG_T, dtype=torch.float32, device=self.device)    # W^T operands, fragment order
+        # GEMM arithmetic of the MFMA kernels: "f32" = v_mfma_f32_32x32x2_f32, "bf16x3" = three-term bf16
+        # split of both operands on v_mfma_f32_32x32x16_bf16 (fp32-accurate, see csrc/mlp_layout.h)
+        self.gemm = os.environ.get("FLY_GEMM", "f32")
+        assert self.gemm in ("f32", "bf16x3")
+        self.PB = torch.zeros(PB_HALVES, dtype=torch.int16, device=self.device)
+        self.PTB = torch.zeros(PTB_HALVES, dtype=torch.int16, device=self.device)
+        idx_fb, idx_tb = build_plane_maps()
+        self.idx_fb = torch.from_numpy(idx_fb).to(self.device)
+        self.idx_tb = torch.from_numpy(idx_tb).to(self.device)
+        self._src_fb = torch.nonzero(self.idx_fb >= 0).squeeze(-1)
+        self._dst_fb = self.idx_fb[self._src_fb].long()
+        self._src_tb = torch.nonzero(self.idx_tb >= 0).squeeze(-1)
+        self._dst_tb = self.idx_tb[self._src_tb].long()
         idx_f, idx_t = build_index_maps()
         self.idx_f = torch.from_numpy(idx_f).to(self.device)
         self.idx_t = torch.from_numpy(idx_t).to(self.device)
@@ -117,10 +173,19 @@ class PackedPolicy:
         with torch.no_grad():
             self.PF[self._dst_f] = self.P[self._src_f]
             self.PT[self._dst_t] = self.P[self._src_t]
+            for dst_buf, src, dst in ((self.PB, self._src_fb, self._dst_fb), (self.PTB, self._src_tb, self._dst_tb)):
+                for term, plane in enumerate(split_bf16x3(self.P[src])):
+                    dst_buf[dst + 512 * term] = plane
         self.version += 1
 
     refresh_transposes = refresh
     version = 0         # bumped whenever the weights change: consumers of cached network outputs compare it
+
+    def pb_ptr(self):
+        return C.c_void_p(self.PB.data_ptr()) if self.gemm == "bf16x3" else None
+
+    def ptb_ptr(self):
+        return C.c_void_p(self.PTB.data_ptr()) if self.gemm == "bf16x3" else None
 
     def forward(self, x, want_mu=True, want_v=True, saves=None):
         """x f32 [..., 73] on the device -> (mu [..., 18] | None, v [..., 1] | None)."""
@@ -134,7 +199,7 @@ class PackedPolicy:
         s = saves or {}
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
         _lib.check(self._lib.mlp_forward(ptr(self.P), ptr(self.PF), ptr(x2), C.c_int64(n), ptr(mu), ptr(v), ptr(s.get("out")),
-                                         ptr(s.get("h1")), ptr(s.get("h2")), ptr(s.get("h3")), _lib.stream_ptr()),
+                                         ptr(s.get("h1")), ptr(s.get("h2")), ptr(s.get("h3")), self.pb_ptr(), _lib.stream_ptr()),
                    "mlp_forward")
         return (mu.view(*lead, NACT) if want_mu else None), (v.view(*lead, 1) if want_v else None)
 
@@ -210,7 +275,7 @@ class PackedPolicy:
                 C.c_int(self._epoch), p(self.tile_wait_error), st), "mlp_forward_backward")
         else:
             _lib.check(self._lib.mlp_forward(p(self.P), p(self.PF), p(x), C.c_int64(n), None, None, p(s["out"]), p(s["h1"]),
-                                             p(s["h2"]), p(s["h3"]), st), "mlp_forward")
+                                             p(s["h2"]), p(s["h3"]), self.pb_ptr(), st), "mlp_forward")
             _lib.check(self._lib.mlp_backward_dx(p(self.PT), p(s["out"]), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(action),
                                                  p(old_logp), p(adv), p(target), p(var), C.c_int64(n), C.c_float(inv_b),
                                                  C.c_float(clip), p(d["dz4"]), p(d["dz3"]), p(d["dz2"]), p(d["dz1"]),

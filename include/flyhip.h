@@ -207,12 +207,21 @@ int ppo_rollout_bookkeeping(const float* reward, int64_t rows, int64_t n, float*
  *   mu_out [n][18]  actor mean (after its ELU)        v_out [n]  critic value
  *   out_save [n][32], h1_save [n][256], h2_save [n][128], h3_save [n][128]: activations kept
  *   for the backward pass.
+ * GEMM arithmetic: with params_b3 = NULL the layers run on v_mfma_f32_32x32x2_f32 (fp32 products,
+ * fp32 accumulate).  With params_b3 = the weights as three bf16 terms each (w = w0 + w1 + w2 exactly,
+ * MLP_PB_HALVES_ABI 16-bit words, layout in mlp_layout.h; mlp_adam_step maintains it) the same GEMMs
+ * run on v_mfma_f32_32x32x16_bf16 with both operands split that way and six product terms per k
+ * block, fp32 accumulate: measured error below the fp32 MFMA chain's (tools/bf16x3_gemm.hip), 2.7x
+ * less matrix time.  Inputs, outputs and saved activations are fp32 either way.
  */
+#define MLP_PB_HALVES_ABI 221184
+#define MLP_PTB_HALVES_ABI 159744
 #define MLP_PACKED_FLOATS_ABI 74272
 #define MLP_FRAG_FLOATS_ABI 73728
 #define MLP_FRAG_T_FLOATS_ABI 53248
-int mlp_forward(const float* params, const float* params_frag, const float* x, int64_t n, float* mu_out, float* v_out,
-                float* out_save, float* h1_save, float* h2_save, float* h3_save, void* stream);
+int mlp_forward(const float* params, const float* params_frag, const float* x, int64_t n,
+                float* mu_out, float* v_out, float* out_save, float* h1_save, float* h2_save,
+                float* h3_save, const uint16_t* params_b3, void* stream);
 /* ppo.py:214-220 in ONE launch: mu = Net.pi(x), act = mu + sqrt(var)*eps, log-prob of the unclipped
  * act, act_out = clip(act, -1, 1).  eps, act_out f32 [n][18]; var f32 [18]; logp_out f32 [n];
  * mu_out f32 [n][18] and v_out f32 [n] (= Net.v(x), the same rows the critic pass of ppo.py:158-159
@@ -223,7 +232,7 @@ int mlp_forward(const float* params, const float* params_frag, const float* x, i
 int mlp_forward_sample(const float* params, const float* params_frag, const float* x, int64_t n,
                        const float* eps, const float* var, int32_t var_steps, float var_decay,
                        float var_min, float* act_out, float* logp_out, float* mu_out, float* v_out,
-                       void* stream);
+                       const uint16_t* params_b3, void* stream);
 
 
 /*

@@ -177,7 +177,7 @@ def test_fused_forward_sample_matches_separate_kernels(n):
     _lib.check(lib.ppo_sample_logprob(p(mu), p(var), p(eps), p(act1), p(lp1), n, None), "sample")
     act2 = torch.empty(n, 18, device="cuda:0"); lp2 = torch.empty(n, device="cuda:0"); mu2 = torch.empty(n, 18, device="cuda:0")
     v2 = torch.empty(n, device="cuda:0")
-    _lib.check(lib.mlp_forward_sample(p(pol.P), p(pol.PF), p(x), n, p(eps), p(var), 0, 0.0, 0.0, p(act2), p(lp2), p(mu2), p(v2), None), "fused")
+    _lib.check(lib.mlp_forward_sample(p(pol.P), p(pol.PF), p(x), n, p(eps), p(var), 0, 0.0, 0.0, p(act2), p(lp2), p(mu2), p(v2), pol.pb_ptr(), None), "fused")
     torch.cuda.synchronize()
     assert torch.equal(mu, mu2) and torch.equal(act1, act2) and torch.equal(v1.view(-1), v2)
     torch.testing.assert_close(lp1, lp2, rtol=2e-6, atol=1e-5)
@@ -237,3 +237,34 @@ def test_rollout_bookkeeping_equals_per_step_calls():
         torch.cuda.synchronize()
         assert torch.equal(s1, s2) and torch.equal(v1, v2)
     assert float(v2[0]) == float(np.float32(0.2))            # dec = 0: untouched
+
+
+@pytest.mark.parametrize("n", [33, 8192])
+def test_bf16x3_forward_is_fp32_accurate(n):
+    """The bf16x3 GEMM path (three-term bf16 split of both operands, six MFMA terms, fp32 accumulate)
+    against an fp64 evaluation of the same network: its error must stay within the fp32 tolerance of
+    this suite (2e-5) and within 2x of the error of the fp32-MFMA path on the same inputs."""
+    from fly_bproject_amd.policy import PackedPolicy
+    from fly_bproject_amd.ppo import Net
+    torch.manual_seed(n + 1)
+    net = Net(73, 18).to("cuda:0")
+    pol = PackedPolicy(net, "cuda:0")
+    pol.init_training(n)
+    x = torch.randn(n, 73, device="cuda:0") * 2.0
+    ref = Net(73, 18).to("cuda:0").double()
+    ref.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+    with torch.no_grad():
+        t = ref.shared_net(x.double())
+        mu64, v64 = ref.to_mean(t), ref.to_value(t)
+        h1_64 = torch.nn.functional.elu(ref.shared_net[0](x.double()))
+    err = {}
+    for mode in ("f32", "bf16x3"):
+        pol.gemm = mode
+        with torch.no_grad():
+            mu, v = pol.forward(x, saves=pol.saves)
+        torch.cuda.synchronize()
+        err[mode] = (float((mu.double() - mu64).abs().max()), float((v.double() - v64).abs().max()),
+                     float((pol.saves["h1"][:n].double() - h1_64).abs().max()))
+        assert torch.isfinite(mu).all() and torch.isfinite(v).all()
+    for a, b in zip(err["bf16x3"], err["f32"]):
+        assert a <= 2e-5 and a <= 2.0 * b + 1e-7, err
