@@ -104,7 +104,8 @@ def kernel_rooflines(num_envs, T, reps):
         epoch[0] += 1
         lib.mlp_forward_backward(p(pol.P), p(pol.PF), p(pol.PT), p(x), rows, p(s["out"]), p(s["h1"]), p(s["h2"]), p(s["h3"]),
                                  p(act), p(olp), p(adv), p(tgt), p(var), 1.0 / rows, 0.2, p(d["dz4"]), p(d["dz3"]),
-                                 p(d["dz2"]), p(d["dz1"]), p(pol.loss_part), p(flags), epoch[0], p(err), _lib.stream_ptr())
+                                 p(d["dz2"]), p(d["dz1"]), p(pol.loss_part), p(flags), epoch[0], p(err), pol.pb_ptr(), pol.ptb_ptr(),
+                                 _lib.stream_ptr())
     t_fb = _time_launches(fwd_bwd, reps)
     assert int(err.item()) == 0, "mlp_forward_backward reported a lost tile flag"
     xs = torch.randn(num_envs, 73, device="cuda:0")

@@ -25,7 +25,7 @@ extern "C" hipError_t flyhip_launch_mlp_backward_dx(const float* PT, const float
                                                     const float* old_logp, const float* adv, const float* target,
                                                     const float* var, int64_t n, float inv_batch, float clip,
                                                     float* dz4, float* dz3, float* dz2, float* dz1, float* loss_part,
-                                                    void* stream);
+                                                    const uint16_t* PTB, void* stream);
 extern "C" int64_t flyhip_mlp_grad_workspace_floats(void);
 extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, const float* h2, const float* h3,
                                                const float* dz1, const float* dz2, const float* dz3, const float* dz4,
@@ -35,6 +35,7 @@ extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PF, float* PT, con
                                              const float* G, const float* mask, float* m,
                                              float* v, int* step, float lr, float beta1, float beta2, float eps,
                                              float max_norm, float grad_scale, float* norm_ws, int norm_ready,
+                                             uint16_t* PB, uint16_t* PTB, const int* idx_fb, const int* idx_tb,
                                              void* stream);
 
 extern "C" hipError_t flyhip_launch_bookkeeping(const float* reward, int64_t n, float* score_acc, float score_scale,
@@ -58,7 +59,8 @@ extern "C" hipError_t flyhip_launch_mlp_fwd_bwd(const float* P, const float* PF,
                                                 const float* action, const float* old_logp, const float* adv,
                                                 const float* target, const float* var, float inv_batch, float clip,
                                                 float* dz4, float* dz3, float* dz2, float* dz1, float* loss_part,
-                                                int* flags, int epoch, int* err, void* stream);
+                                                int* flags, int epoch, int* err, const uint16_t* PB, const uint16_t* PTB,
+                                                void* stream);
 extern "C" hipError_t flyhip_launch_rollout_bookkeeping(const float* reward, int64_t rows, int64_t n, float* terms,
                                                         float* score_acc, float score_scale, float* action_var, int nvar,
                                                         float var_decay, float var_min, void* stream);
@@ -277,7 +279,7 @@ int mlp_backward_dx(const float* params_t, const float* out_saved, const float* 
                     const float* h2_saved, const float* h3_saved, const float* action,
                     const float* old_logp, const float* adv, const float* target, const float* var,
                     int64_t n, float inv_batch, float clip, float* dz4, float* dz3, float* dz2,
-                    float* dz1, float* loss_part, void* stream)
+                    float* dz1, float* loss_part, const uint16_t* params_t_b3, void* stream)
 {
     if (!params_t || !out_saved || !h1_saved || !h2_saved || !h3_saved || !action || !old_logp || !adv ||
         !target || !var || !dz4 || !dz3 || !dz2 || !dz1)
@@ -285,7 +287,7 @@ int mlp_backward_dx(const float* params_t, const float* out_saved, const float* 
     if (n <= 0) return fail(FLY_E_ARG, "mlp_backward_dx: n must be > 0");
     hipError_t e = flyhip_launch_mlp_backward_dx(params_t, out_saved, h1_saved, h2_saved, h3_saved, action, old_logp,
                                                  adv, target, var, n, inv_batch, clip, dz4, dz3, dz2, dz1, loss_part,
-                                                 stream);
+                                                 params_t_b3, stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_backward_dx launch");
     return FLY_OK;
 }
@@ -295,8 +297,11 @@ int mlp_forward_backward(const float* params, const float* params_frag, const fl
                          float* h3_save, const float* action, const float* old_logp, const float* adv,
                          const float* target, const float* var, float inv_batch, float clip,
                          float* dz4, float* dz3, float* dz2, float* dz1, float* loss_part,
-                         int32_t* flags, int32_t epoch, int32_t* err, void* stream)
+                         int32_t* flags, int32_t epoch, int32_t* err, const uint16_t* params_b3,
+                         const uint16_t* params_t_b3, void* stream)
 {
+    if ((params_b3 == nullptr) != (params_t_b3 == nullptr))
+        return fail(FLY_E_ARG, "mlp_forward_backward: params_b3 and params_t_b3 go together");
     if (!params || !params_frag || !params_t_frag || !x || !out_save || !h1_save || !h2_save || !h3_save || !action ||
         !old_logp || !adv || !target || !var || !dz4 || !dz3 || !dz2 || !dz1 || !flags || !err)
         return fail(FLY_E_ARG, "mlp_forward_backward: null pointer");
@@ -304,7 +309,7 @@ int mlp_forward_backward(const float* params, const float* params_frag, const fl
     if (epoch <= 0 || epoch >= (1 << 27)) return fail(FLY_E_ARG, "mlp_forward_backward: epoch must be in [1, 2^27)");
     hipError_t e = flyhip_launch_mlp_fwd_bwd(params, params_frag, params_t_frag, x, n, out_save, h1_save, h2_save, h3_save,
                                              action, old_logp, adv, target, var, inv_batch, clip, dz4, dz3, dz2, dz1,
-                                             loss_part, flags, epoch, err, stream);
+                                             loss_part, flags, epoch, err, params_b3, params_t_b3, stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_forward_backward launch");
     return FLY_OK;
 }
@@ -328,13 +333,17 @@ int mlp_grad_w(const float* x, const float* h1_saved, const float* h2_saved, con
 int mlp_adam_step(float* params, float* params_frag, float* params_t_frag, const int32_t* idx_frag,
                   const int32_t* idx_t_frag, const float* grad, const float* mask, float* exp_avg,
                   float* exp_avg_sq, int32_t* step, float lr, float beta1, float beta2, float eps,
-                  float max_norm, float grad_scale, float* norm_ws, int32_t norm_ready, void* stream)
+                  float max_norm, float grad_scale, float* norm_ws, int32_t norm_ready, uint16_t* params_b3,
+                  uint16_t* params_t_b3, const int32_t* idx_b3, const int32_t* idx_t_b3, void* stream)
 {
+    if (params_b3 && (!params_t_b3 || !idx_b3 || !idx_t_b3))
+        return fail(FLY_E_ARG, "mlp_adam_step: params_b3 needs params_t_b3, idx_b3 and idx_t_b3");
     if (!params || !params_frag || !params_t_frag || !idx_frag || !idx_t_frag || !grad || !mask || !exp_avg ||
         !exp_avg_sq || !step || !norm_ws)
         return fail(FLY_E_ARG, "mlp_adam_step: null pointer");
     hipError_t e = flyhip_launch_mlp_adam(params, params_frag, params_t_frag, idx_frag, idx_t_frag, grad, mask, exp_avg, exp_avg_sq, step, lr, beta1, beta2,
-                                          eps, max_norm, grad_scale, norm_ws, norm_ready, stream);
+                                          eps, max_norm, grad_scale, norm_ws, norm_ready, params_b3, params_t_b3, idx_b3, idx_t_b3,
+                                          stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_adam_step launch");
     return FLY_OK;
 }

@@ -996,6 +996,148 @@ __device__ __forceinline__ void backward_body(
     }
 }
 
+// dZ = (hi + lo) * ELU'(H) of the bf16x3 path: fp32 rows to HBM, three bf16 terms to the next GEMM's LDS tile
+template <int N>
+__device__ __forceinline__ void epilogue_dact_b3(const f32x16& hi, const f32x16& lo, const HFrag<1>& hf, int col0,
+                                                 u16* lds_plane0, float* __restrict__ gtile, int nvalid, int lane)
+{
+    const int r = lane & 31;
+    float4 z[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 hv = hf.v[0][g];
+        z[g].x = (hi[4 * g + 0] + lo[4 * g + 0]) * elu_grad_from_out(hv.x);
+        z[g].y = (hi[4 * g + 1] + lo[4 * g + 1]) * elu_grad_from_out(hv.y);
+        z[g].z = (hi[4 * g + 2] + lo[4 * g + 2]) * elu_grad_from_out(hv.z);
+        z[g].w = (hi[4 * g + 3] + lo[4 * g + 3]) * elu_grad_from_out(hv.w);
+        if (lds_plane0) store_split4<N>(lds_plane0, r, col0 + acc_n(g, lane), z[g]);
+    }
+    if (r < nvalid) {
+        float* grow = gtile + r * N + col0 + acc_n(0, lane);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(grow + 8 * g) = z[g];
+    }
+}
+
+constexpr int BW_B3_LDS_FLOATS = 2 * B3_TILE_FLOATS + 2 * BM;
+
+__device__ __forceinline__ void backward_body_b3(
+    float* lds, const long tile,
+    const u16* __restrict__ PTB, const float* __restrict__ out_saved, const float* __restrict__ h1_saved,
+    const float* __restrict__ h2_saved, const float* __restrict__ h3_saved,
+    const float* __restrict__ action, const float* __restrict__ old_logp, const float* __restrict__ adv,
+    const float* __restrict__ target, const float* __restrict__ var, long n, float inv_batch, float clip,
+    float* __restrict__ dz4, float* __restrict__ dz3, float* __restrict__ dz2, float* __restrict__ dz1,
+    float* __restrict__ loss_part)
+{
+    u16* ldsZ2 = reinterpret_cast<u16*>(lds);                     // dZ2: three [32][136] term planes
+    u16* ldsZ3 = reinterpret_cast<u16*>(lds + B3_TILE_FLOATS);    // dZ3: three [32][136] term planes
+    u16* ldsZ4 = ldsZ2;                                           // dZ4 ([32][40] planes) is dead before dZ2 is written
+    float* rowloss = lds + 2 * B3_TILE_FLOATS;                        // [32][2]: policy term, Huber term of each row
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR: weight bases become scalar
+    const long row0 = tile * BM;
+    const int nvalid = (int)(n - row0 < BM ? n - row0 : BM);                // rows of this tile that exist
+
+    WeightHead3 wt4, wt3;
+    gemm_prefetch_b3<MLP_OUT>(wt4, PTB + MLP_OFF_PTB4, wave, lane);
+    HFrag<1> hf3;
+    hfrag_load<MLP_H3, 1>(hf3, h3_saved + row0 * MLP_H3, nvalid, wave * 32, lane);     // in flight during the loss phase
+
+    // Loss gradient at the outputs, one thread per (row, output column): the 32 lanes of a row
+    // reduce the Mahalanobis term and log-determinant with a fixed xor butterfly, every lane then
+    // holds the row's d loss / d logp and writes its own column of dZ4 (HBM + the LDS operand).
+    {
+        const float* out_t = out_saved + row0 * MLP_OUT;       // wave-uniform tile bases, 32-bit lane offsets
+        const float* act_t = action + row0 * MLP_NACT;
+        const float* olp_t = old_logp + row0;
+        const float* adv_t = adv + row0;
+        const float* tgt_t = target + row0;
+        float* dz4_t = dz4 + row0 * MLP_OUT;
+        const int col = tid & 31;
+        const bool act = col < MLP_NACT;
+        const float L = act ? sqrtf(var[col]) : 1.0f;
+        const float var_col = act ? var[col] : 1.0f;
+        float half_log_det = act ? logf(L) : 0.0f;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) half_log_det += __shfl_xor(half_log_det, o, 32);
+#pragma unroll
+        for (int k = 0; k < BM * MLP_OUT / THREADS; ++k) {
+            const int row = (tid >> 5) + k * (THREADS / 32);
+            const bool in = row < nvalid;
+            const float y = in ? out_t[row * MLP_OUT + col] : 0.0f;                   // mean (cols 0..17), value (col 18)
+            const float a = (in && act) ? act_t[row * MLP_NACT + col] : 0.0f;
+            const float xj = act ? (a - y) / L : 0.0f;
+            float M = xj * xj;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) M += __shfl_xor(M, o, 32);
+            float d = 0.0f, pol = 0.0f, hub = 0.0f;
+            if (in) {
+                const float logp = -0.5f * (33.08178959434617f + M) - half_log_det;
+                const float ratio = expf(logp - olp_t[row]);
+                const float A = adv_t[row];
+                const float s1 = ratio * A;
+                const float rc = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+                const float s2 = rc * A;
+                const float in_range = (ratio >= 1.0f - clip && ratio <= 1.0f + clip) ? 1.0f : 0.0f;
+                float dmin;                                    // d min(s1,s2) / d ratio
+                if (s1 < s2) dmin = A;
+                else if (s1 > s2) dmin = A * in_range;
+                else dmin = 0.5f * (A + A * in_range);
+                const float c = -inv_batch * ratio * dmin;     // d loss / d logp
+                pol = -fminf(s1, s2);
+                const float dv = __shfl(y, MLP_NACT, 32) - tgt_t[row];
+                hub = fabsf(dv) < 1.0f ? 0.5f * dv * dv : fabsf(dv) - 0.5f;
+                if (act) d = c * (a - y) / var_col * elu_grad_from_out(y);
+                else if (col == MLP_NACT) d = inv_batch * fminf(fmaxf(dv, -1.0f), 1.0f);   // smooth_l1', beta = 1
+                dz4_t[row * MLP_OUT + col] = d;
+            }
+            {
+                u16 sa, sb, sc;
+                split3(d, sa, sb, sc);
+                u16* q = ldsZ4 + row * (MLP_OUT + B3_PAD) + col;
+                q[0] = sa; q[b3_plane<MLP_OUT>()] = sb; q[2 * b3_plane<MLP_OUT>()] = sc;
+            }
+            if (col == 0) { rowloss[2 * row] = pol; rowloss[2 * row + 1] = hub; }
+        }
+    }
+    __syncthreads();
+    if (tid < 32 && loss_part) {       // fixed-order sum of the 32 rows' loss terms
+        float pol = rowloss[2 * tid], hub = rowloss[2 * tid + 1];
+        for (int o = 16; o > 0; o >>= 1) { pol += __shfl_down(pol, o, 32); hub += __shfl_down(hub, o, 32); }
+        if (tid == 0) { loss_part[2 * tile] = pol; loss_part[2 * tile + 1] = hub; }
+    }
+    HFrag<1> hf2;
+    {   // dA3 = dZ4 . W4  ->  dZ3
+        f32x16 hi, lo;
+        tile_gemm_b3<MLP_OUT>(wt4, PTB + MLP_OFF_PTB4, wave, ldsZ4, hi, lo, lane);
+        gemm_prefetch_b3<MLP_H3>(wt3, PTB + MLP_OFF_PTB3, wave, lane);        // both land during the epilogue + barrier
+        hfrag_load<MLP_H2, 1>(hf2, h2_saved + row0 * MLP_H2, nvalid, wave * 32, lane);
+        epilogue_dact_b3<MLP_H3>(hi, lo, hf3, wave * 32, ldsZ3, dz3 + row0 * MLP_H3, nvalid, lane);
+    }
+    __syncthreads();
+    WeightHead3 wt2;
+    HFrag<1> hf1;
+    {   // dA2 = dZ3 . W3  ->  dZ2
+        f32x16 hi, lo;
+        tile_gemm_b3<MLP_H3>(wt3, PTB + MLP_OFF_PTB3, wave, ldsZ3, hi, lo, lane);
+        gemm_prefetch_b3<MLP_H2>(wt2, PTB + MLP_OFF_PTB2, wave * 2, lane);
+        epilogue_dact_b3<MLP_H2>(hi, lo, hf2, wave * 32, ldsZ2, dz2 + row0 * MLP_H2, nvalid, lane);
+    }
+    __syncthreads();
+    {   // dA1 = dZ2 . W2  ->  dZ1 (no later GEMM reads it: HBM only): this wave's two column tiles in turn
+        WeightHead3 wt2b;
+        HFrag<1> hf1b;
+        hfrag_load<MLP_H1, 1>(hf1, h1_saved + row0 * MLP_H1, nvalid, wave * 64, lane);              // lands during the MFMAs
+        f32x16 hi, lo;
+        tile_gemm_b3<MLP_H2>(wt2, PTB + MLP_OFF_PTB2, wave * 2, ldsZ2, hi, lo, lane);
+        gemm_prefetch_b3<MLP_H2>(wt2b, PTB + MLP_OFF_PTB2, wave * 2 + 1, lane);
+        hfrag_load<MLP_H1, 1>(hf1b, h1_saved + row0 * MLP_H1, nvalid, wave * 64 + 32, lane);
+        epilogue_dact_b3<MLP_H1>(hi, lo, hf1, wave * 64, nullptr, dz1 + row0 * MLP_H1, nvalid, lane);
+        tile_gemm_b3<MLP_H2>(wt2b, PTB + MLP_OFF_PTB2, wave * 2 + 1, ldsZ2, hi, lo, lane);
+        epilogue_dact_b3<MLP_H1>(hi, lo, hf1b, wave * 64 + 32, nullptr, dz1 + row0 * MLP_H1, nvalid, lane);
+    }
+}
+
 __global__ __launch_bounds__(THREADS, WGS_PER_CU) void mlp_backward_dx_kernel(
     const float* __restrict__ PT, const float* __restrict__ out_saved, const float* __restrict__ h1_saved,
     const float* __restrict__ h2_saved, const float* __restrict__ h3_saved,
@@ -1007,6 +1149,19 @@ __global__ __launch_bounds__(THREADS, WGS_PER_CU) void mlp_backward_dx_kernel(
     __shared__ __attribute__((aligned(16))) float lds[BW_FLOATS];
     backward_body(lds, blockIdx.x, PT, out_saved, h1_saved, h2_saved, h3_saved, action,
                   old_logp, adv, target, var, n, inv_batch, clip, dz4, dz3, dz2, dz1, loss_part);
+}
+
+__global__ __launch_bounds__(THREADS, 2) void mlp_backward_dx_b3_kernel(
+    const u16* __restrict__ PTB, const float* __restrict__ out_saved, const float* __restrict__ h1_saved,
+    const float* __restrict__ h2_saved, const float* __restrict__ h3_saved,
+    const float* __restrict__ action, const float* __restrict__ old_logp, const float* __restrict__ adv,
+    const float* __restrict__ target, const float* __restrict__ var, long n, float inv_batch, float clip,
+    float* __restrict__ dz4, float* __restrict__ dz3, float* __restrict__ dz2, float* __restrict__ dz1,
+    float* __restrict__ loss_part)
+{
+    __shared__ __attribute__((aligned(16))) float lds[BW_B3_LDS_FLOATS];
+    backward_body_b3(lds, blockIdx.x, PTB, out_saved, h1_saved, h2_saved, h3_saved, action, old_logp, adv, target, var, n,
+                     inv_batch, clip, dz4, dz3, dz2, dz1, loss_part);
 }
 
 // Forward and backward of one minibatch in ONE launch of 2 * tiles workgroups.  Both are row-local:
@@ -1038,9 +1193,12 @@ __device__ __forceinline__ unsigned long long realtime_cu()
     return (t & 0xffffffffffffull) | ((unsigned long long)(((hw >> 8) & 0xff) | ((xcc & 0xf) << 8)) << 48);
 }
 
-template <bool STAMP>
-__global__ __launch_bounds__(THREADS, WGS_PER_CU) void mlp_fwd_bwd_kernel(
-    const float* __restrict__ P, const float* __restrict__ PF, const float* __restrict__ PT,
+constexpr int FB_B3_LDS_FLOATS = FWD_B3_LDS_FLOATS > BW_B3_LDS_FLOATS ? FWD_B3_LDS_FLOATS : BW_B3_LDS_FLOATS;
+
+// B3: the bf16x3 GEMM bodies (PF/PT then point at the 16-bit term planes PB/PTB)
+template <bool STAMP, bool B3>
+__global__ __launch_bounds__(THREADS, B3 ? 2 : WGS_PER_CU) void mlp_fwd_bwd_kernel(
+    const float* __restrict__ P, const void* __restrict__ PF, const void* __restrict__ PT,
     const float* __restrict__ x, long n, float* __restrict__ out_save, float* __restrict__ h1_save,
     float* __restrict__ h2_save, float* __restrict__ h3_save,
     const float* __restrict__ action, const float* __restrict__ old_logp, const float* __restrict__ adv,
@@ -1049,7 +1207,7 @@ __global__ __launch_bounds__(THREADS, WGS_PER_CU) void mlp_fwd_bwd_kernel(
     float* __restrict__ loss_part, int* __restrict__ flags, int epoch, int* __restrict__ err,
     unsigned long long* __restrict__ stamps)
 {
-    __shared__ __attribute__((aligned(16))) float lds[FB_LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[B3 ? FB_B3_LDS_FLOATS : FB_LDS_FLOATS];
     __shared__ int ok;
     if (STAMP && threadIdx.x == 0) stamps[4L * blockIdx.x] = realtime_cu();
     const long tiles = (n + BM - 1) / BM;
@@ -1057,8 +1215,12 @@ __global__ __launch_bounds__(THREADS, WGS_PER_CU) void mlp_fwd_bwd_kernel(
     if ((long)blockIdx.x < pad_tiles) {
         const long tile = blockIdx.x;
         if (tile >= tiles) return;
-        forward_body<false>(lds, tile, tiles, P, PF, x, n, nullptr, nullptr, out_save, h1_save,
-                            h2_save, h3_save, nullptr, nullptr, nullptr, nullptr, nullptr);
+        if (B3)
+            forward_body_b3<false>(lds, tile, tiles, P, static_cast<const u16*>(PF), x, n, nullptr, nullptr, out_save, h1_save,
+                                   h2_save, h3_save, nullptr, nullptr, nullptr, nullptr, nullptr);
+        else
+            forward_body<false>(lds, tile, tiles, P, static_cast<const float*>(PF), x, n, nullptr, nullptr, out_save, h1_save,
+                                h2_save, h3_save, nullptr, nullptr, nullptr, nullptr, nullptr);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);                    // this thread's stores have been acknowledged by L2
         __syncthreads();
@@ -1087,8 +1249,12 @@ __global__ __launch_bounds__(THREADS, WGS_PER_CU) void mlp_fwd_bwd_kernel(
         if (ok) return;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // ordering only: no cache maintenance (see above)
         if (STAMP && threadIdx.x == 0) stamps[4L * blockIdx.x + 2] = realtime_cu();
-        backward_body(lds, tile, PT, out_save, h1_save, h2_save, h3_save, action, old_logp, adv, target, var, n, inv_batch,
-                      clip, dz4, dz3, dz2, dz1, loss_part);
+        if (B3)
+            backward_body_b3(lds, tile, static_cast<const u16*>(PT), out_save, h1_save, h2_save, h3_save, action, old_logp, adv,
+                             target, var, n, inv_batch, clip, dz4, dz3, dz2, dz1, loss_part);
+        else
+            backward_body(lds, tile, static_cast<const float*>(PT), out_save, h1_save, h2_save, h3_save, action, old_logp, adv,
+                          target, var, n, inv_batch, clip, dz4, dz3, dz2, dz1, loss_part);
         if (STAMP && threadIdx.x == 0) {
             __builtin_amdgcn_s_waitcnt(0);
             stamps[4L * blockIdx.x + 1] = realtime_cu();
@@ -1421,7 +1587,10 @@ __global__ __launch_bounds__(ADAM_THREADS) void mlp_adam_apply_kernel(float* __r
                                                                       const int* __restrict__ step, float lr, float beta1,
                                                                       float beta2, float eps, float max_norm,
                                                                       float grad_scale, float* __restrict__ norm_ws,
-                                                                      int nparts, float part_scale)
+                                                                      int nparts, float part_scale,
+                                                                      u16* __restrict__ PB, u16* __restrict__ PTB,
+                                                                      const int* __restrict__ idx_fb,
+                                                                      const int* __restrict__ idx_tb)
 {
     __shared__ float s_coef;
     __shared__ float red[16];
@@ -1463,6 +1632,13 @@ __global__ __launch_bounds__(ADAM_THREADS) void mlp_adam_apply_kernel(float* __r
     const int jf = idx_f[i], jt = idx_t[i];
     if (jf >= 0) PF[jf] = p;
     if (jt >= 0) PT[jt] = p;
+    if (PB) {       // and the three-term bf16 planes of the bf16x3 GEMM path
+        u16 a, b, c;
+        split3(p, a, b, c);
+        const int kf = idx_fb[i], kt = idx_tb[i];
+        if (kf >= 0) { PB[kf] = a; PB[kf + 512] = b; PB[kf + 1024] = c; }
+        if (kt >= 0) { PTB[kt] = a; PTB[kt + 512] = b; PTB[kt + 1024] = c; }
+    }
 }
 
 }  // namespace
@@ -1531,8 +1707,14 @@ extern "C" hipError_t flyhip_launch_mlp_backward_dx(const float* PT, const float
                                                     const float* old_logp, const float* adv, const float* target,
                                                     const float* var, int64_t n, float inv_batch, float clip,
                                                     float* dz4, float* dz3, float* dz2, float* dz1, float* loss_part,
-                                                    void* stream)
+                                                    const uint16_t* PTB, void* stream)
 {
+    if (PTB) {
+        hipLaunchKernelGGL(mlp_backward_dx_b3_kernel, dim3((unsigned)((n + BM - 1) / BM)), dim3(THREADS), 0, (hipStream_t)stream,
+                           PTB, out_saved, h1, h2, h3, action, old_logp, adv, target, var, (long)n, inv_batch, clip, dz4, dz3,
+                           dz2, dz1, loss_part);
+        return hipGetLastError();
+    }
     const int grid = (int)((n + BM - 1) / BM);
     hipLaunchKernelGGL(mlp_backward_dx_kernel, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, PT, out_saved,
                        h1, h2, h3, action, old_logp, adv, target, var, (long)n, inv_batch, clip, dz4, dz3, dz2, dz1,
@@ -1548,13 +1730,21 @@ extern "C" hipError_t flyhip_launch_mlp_fwd_bwd(const float* P, const float* PF,
                                                 const float* action, const float* old_logp, const float* adv,
                                                 const float* target, const float* var, float inv_batch, float clip,
                                                 float* dz4, float* dz3, float* dz2, float* dz1, float* loss_part,
-                                                int* flags, int epoch, int* err, void* stream)
+                                                int* flags, int epoch, int* err, const uint16_t* PB, const uint16_t* PTB,
+                                                void* stream)
 {
     const long tiles = (n + BM - 1) / BM;
     const long pad_tiles = (tiles + 7) & ~7L;
-    hipLaunchKernelGGL(mlp_fwd_bwd_kernel<false>, dim3((unsigned)(pad_tiles + tiles)), dim3(THREADS), 0, (hipStream_t)stream, P,
-                       PF, PT, x, (long)n, out_save, h1_save, h2_save, h3_save, action, old_logp, adv, target, var, inv_batch,
-                       clip, dz4, dz3, dz2, dz1, loss_part, flags, epoch, err, (unsigned long long*)nullptr);
+    if (PB && PTB)
+        hipLaunchKernelGGL((mlp_fwd_bwd_kernel<false, true>), dim3((unsigned)(pad_tiles + tiles)), dim3(THREADS), 0,
+                           (hipStream_t)stream, P, (const void*)PB, (const void*)PTB, x, (long)n, out_save, h1_save, h2_save,
+                           h3_save, action, old_logp, adv, target, var, inv_batch, clip, dz4, dz3, dz2, dz1, loss_part, flags,
+                           epoch, err, (unsigned long long*)nullptr);
+    else
+        hipLaunchKernelGGL((mlp_fwd_bwd_kernel<false, false>), dim3((unsigned)(pad_tiles + tiles)), dim3(THREADS), 0,
+                           (hipStream_t)stream, P, (const void*)PF, (const void*)PT, x, (long)n, out_save, h1_save, h2_save,
+                           h3_save, action, old_logp, adv, target, var, inv_batch, clip, dz4, dz3, dz2, dz1, loss_part, flags,
+                           epoch, err, (unsigned long long*)nullptr);
     return hipGetLastError();
 }
 
@@ -1568,8 +1758,8 @@ extern "C" int flyhip_debug_mlp_fwd_bwd_stamped(const float* P, const float* PF,
 {
     const long tiles = (n + BM - 1) / BM;
     const long pad_tiles = (tiles + 7) & ~7L;
-    hipLaunchKernelGGL(mlp_fwd_bwd_kernel<true>, dim3((unsigned)(pad_tiles + tiles)), dim3(THREADS), 0, (hipStream_t)stream, P,
-                       PF, PT, x, (long)n, out_save, h1_save, h2_save, h3_save, action, old_logp, adv, target, var, inv_batch,
+    hipLaunchKernelGGL((mlp_fwd_bwd_kernel<true, false>), dim3((unsigned)(pad_tiles + tiles)), dim3(THREADS), 0, (hipStream_t)stream, P,
+                       (const void*)PF, (const void*)PT, x, (long)n, out_save, h1_save, h2_save, h3_save, action, old_logp, adv, target, var, inv_batch,
                        clip, dz4, dz3, dz2, dz1, loss_part, flags, epoch, err, stamps);
     return (int)hipGetLastError();
 }
@@ -1624,6 +1814,7 @@ extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PF, float* PT, con
                                              const float* G, const float* mask, float* m,
                                              float* v, int* step, float lr, float beta1, float beta2, float eps,
                                              float max_norm, float grad_scale, float* norm_ws, int norm_ready,
+                                             uint16_t* PB, uint16_t* PTB, const int* idx_fb, const int* idx_tb,
                                              void* stream)
 {
     int nparts = ADAM_BLOCKS;
@@ -1639,6 +1830,6 @@ extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PF, float* PT, con
     }
     hipLaunchKernelGGL(mlp_adam_apply_kernel, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, P, PF, PT,
                        idx_f, idx_t, G, mask, m, v, step, lr, beta1, beta2, eps, max_norm, grad_scale, norm_ws, nparts,
-                       part_scale);
+                       part_scale, PB, PTB, idx_fb, idx_tb);
     return hipGetLastError();
 }

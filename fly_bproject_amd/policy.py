@@ -272,14 +272,14 @@ class PackedPolicy:
                 p(self.P), p(self.PF), p(self.PT), p(x), C.c_int64(n), p(s["out"]), p(s["h1"]), p(s["h2"]), p(s["h3"]),
                 p(action), p(old_logp), p(adv), p(target), p(var), C.c_float(inv_b), C.c_float(clip),
                 p(d["dz4"]), p(d["dz3"]), p(d["dz2"]), p(d["dz1"]), p(self.loss_part), p(self._tile_flags),
-                C.c_int(self._epoch), p(self.tile_wait_error), st), "mlp_forward_backward")
+                C.c_int(self._epoch), p(self.tile_wait_error), self.pb_ptr(), self.ptb_ptr(), st), "mlp_forward_backward")
         else:
             _lib.check(self._lib.mlp_forward(p(self.P), p(self.PF), p(x), C.c_int64(n), None, None, p(s["out"]), p(s["h1"]),
                                              p(s["h2"]), p(s["h3"]), self.pb_ptr(), st), "mlp_forward")
             _lib.check(self._lib.mlp_backward_dx(p(self.PT), p(s["out"]), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(action),
                                                  p(old_logp), p(adv), p(target), p(var), C.c_int64(n), C.c_float(inv_b),
                                                  C.c_float(clip), p(d["dz4"]), p(d["dz3"]), p(d["dz2"]), p(d["dz1"]),
-                                                 p(self.loss_part), st), "mlp_backward_dx")
+                                                 p(self.loss_part), self.ptb_ptr(), st), "mlp_backward_dx")
         nm = (p(self.grad_mask), p(self._norm_ws), p(self.step)) if fuse_norm else (None, None, None)
         _lib.check(self._lib.mlp_grad_w(p(x), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(d["dz1"]), p(d["dz2"]),
                                         p(d["dz3"]), p(d["dz4"]), C.c_int64(n), p(self.workspace), p(self.G), *nm, st),
@@ -298,4 +298,5 @@ class PackedPolicy:
                                            p(self.exp_avg_sq), p(self.step), C.c_float(self.lr),
                                            C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
                                            C.c_float(self.max_norm), C.c_float(grad_scale), p(self._norm_ws),
-                                           C.c_int(1 if norm_ready else 0), _lib.stream_ptr()), "mlp_adam_step")
+                                           C.c_int(1 if norm_ready else 0), p(self.PB), p(self.PTB), p(self.idx_fb),
+                                           p(self.idx_tb), _lib.stream_ptr()), "mlp_adam_step")

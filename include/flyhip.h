@@ -251,7 +251,9 @@ int mlp_forward_sample(const float* params, const float* params_frag, const floa
  *   mlp_adam_step   : grad *= grad_scale; clip_grad_norm_(max_norm); Adam with torch defaults on
  *                     `params`; every updated weight is also scattered into params_frag /
  *                     params_t_frag through idx_frag / idx_t_frag (int32 [MLP_PACKED_FLOATS_ABI],
- *                     -1 = no copy).  `mask` (packed layout, 0/1)
+ *                     -1 = no copy); with params_b3 != NULL also its three bf16 terms into
+ *                     params_b3 / params_t_b3 (term 0 at idx_b3[i] / idx_t_b3[i], terms 1 and 2
+ *                     512 and 1024 16-bit words later).  `mask` (packed layout, 0/1)
  *                     freezes padding and structural zeros.  `step` is a device int counter;
  *                     `norm_ws` is a device scratch of >= 1280 floats, norm_ws[0] returns the
  *                     pre-clip gradient norm.
@@ -261,7 +263,7 @@ int mlp_backward_dx(const float* params_t_frag, const float* out_saved, const fl
                     const float* h2_saved, const float* h3_saved, const float* action,
                     const float* old_logp, const float* adv, const float* target, const float* var,
                     int64_t n, float inv_batch, float clip, float* dz4, float* dz3, float* dz2,
-                    float* dz1, float* loss_part, void* stream);
+                    float* dz1, float* loss_part, const uint16_t* params_t_b3, void* stream);
 
 /* mlp_forward (activations saved) and mlp_backward_dx of the same n rows in ONE launch: both are
  * row-local, so the backward workgroup of a 32-row tile starts as soon as that tile's forward has
@@ -272,13 +274,15 @@ int mlp_backward_dx(const float* params_t_frag, const float* out_saved, const fl
  * 1 = a workgroup gave up waiting for its tile (the wait is bounded, a lost flag cannot hang the
  * device), 2 = a tile's forward and backward workgroups were not placed on the same XCD, which the
  * kernel relies on instead of L2 write-back/invalidate per workgroup.  Non-zero => results of
- * that call are invalid; use mlp_forward + mlp_backward_dx instead. */
+ * that call are invalid; use mlp_forward + mlp_backward_dx instead.  params_b3 / params_t_b3
+ * (both or neither) select the bf16x3 GEMM arithmetic, see mlp_forward. */
 int mlp_forward_backward(const float* params, const float* params_frag, const float* params_t_frag,
                          const float* x, int64_t n, float* out_save, float* h1_save, float* h2_save,
                          float* h3_save, const float* action, const float* old_logp, const float* adv,
                          const float* target, const float* var, float inv_batch, float clip,
                          float* dz4, float* dz3, float* dz2, float* dz1, float* loss_part,
-                         int32_t* flags, int32_t epoch, int32_t* err, void* stream);
+                         int32_t* flags, int32_t epoch, int32_t* err, const uint16_t* params_b3,
+                         const uint16_t* params_t_b3, void* stream);
 int mlp_grad_w(const float* x, const float* h1_saved, const float* h2_saved, const float* h3_saved,
                const float* dz1, const float* dz2, const float* dz3, const float* dz4, int64_t n,
                float* workspace, float* grad, const float* norm_mask, float* norm_ws, int32_t* norm_step,
@@ -286,7 +290,9 @@ int mlp_grad_w(const float* x, const float* h1_saved, const float* h2_saved, con
 int mlp_adam_step(float* params, float* params_frag, float* params_t_frag, const int32_t* idx_frag,
                   const int32_t* idx_t_frag, const float* grad, const float* mask, float* exp_avg,
                   float* exp_avg_sq, int32_t* step, float lr, float beta1, float beta2, float eps,
-                  float max_norm, float grad_scale, float* norm_ws, int32_t norm_ready, void* stream);
+                  float max_norm, float grad_scale, float* norm_ws, int32_t norm_ready,
+                  uint16_t* params_b3, uint16_t* params_t_b3, const int32_t* idx_b3,
+                  const int32_t* idx_t_b3, void* stream);
 
 
 /*

@@ -203,3 +203,35 @@ def test_one_launch_forward_backward_equals_two_launches(n):
         else:
             res[False] = got
     assert int(pol.tile_wait_error.item()) == 0 and pol._epoch == e0 + 2
+
+
+def test_bf16x3_training_step_matches_fp32_path():
+    """One minibatch gradient + Adam step with the bf16x3 GEMMs (forward, dX chain; dW stays on fp32
+    MFMA) against the fp32-MFMA path and torch autograd: same loss and gradients to the suite's fp32
+    tolerance, and the bf16 term planes the Adam kernel scatters equal a fresh split of the weights."""
+    from fly_bproject_amd.policy import split_bf16x3
+    n = 4099
+    net, ref, pol, (x, action, old_logp, adv, target, var) = _setup(n, 21)
+    res = {}
+    for mode in ("f32", "bf16x3"):
+        pol.gemm = mode
+        for fuse in (False, True):
+            pol.fuse_fwd_bwd = fuse
+            pol.minibatch_grad(x, action, old_logp, adv, target, var, 0.2)
+            torch.cuda.synchronize()
+            res[(mode, fuse)] = (pol.G.clone(), float(pol.loss_value(n)), pol.dz["dz1"][:n].clone())
+    assert torch.equal(res[("bf16x3", False)][0], res[("bf16x3", True)][0])       # one launch == two launches, bit for bit
+    g32, l32, z32 = res[("f32", True)]
+    g3, l3, z3 = res[("bf16x3", True)]
+    assert abs(l3 - l32) <= 2e-6 * max(1.0, abs(l32))
+    torch.testing.assert_close(g3, g32, rtol=2e-4, atol=2e-7)
+    torch.testing.assert_close(z3, z32, rtol=2e-4, atol=1e-9)
+    agent = _bare_agent(ref, var)
+    loss = agent.minibatch_loss(x, action, old_logp, target.unsqueeze(-1), adv.unsqueeze(-1))
+    assert abs(l3 - float(loss)) <= 2e-5 * max(1.0, abs(float(loss)))
+    pol.adam_step()
+    torch.cuda.synchronize()
+    assert int(pol.tile_wait_error.item()) == 0
+    for buf, src, dst in ((pol.PB, pol._src_fb, pol._dst_fb), (pol.PTB, pol._src_tb, pol._dst_tb)):
+        for term, plane in enumerate(split_bf16x3(pol.P[src])):
+            assert torch.equal(buf[dst + 512 * term], plane)
