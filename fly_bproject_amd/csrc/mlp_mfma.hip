@@ -131,6 +131,13 @@ __device__ __forceinline__ void tile_gemm(const float* __restrict__ Wf, int tile
 // C/D layout of the 32x32 tile with the operand roles above: lane holds row (lane&31) and output
 // columns n = 8*g + 4*(lane>>5) + j for register 4*g + j.
 __device__ __forceinline__ int acc_n(int g, int lane) { return 8 * g + 4 * (lane >> 5); }
+// Saved activations and dZ tensors ([rows][N], written by these epilogues, read back by the
+// backward epilogues and the dW kernel) live in HBM in TILE-FRAGMENT order: per 32-row tile and
+// 32-column tile one block of 1024 floats laid out [g][lane][4] exactly like the accumulator
+// fragments, so a wave's store or load of one register group is one contiguous KiB (row-major rows
+// would be 32-byte pieces of 32 different lines: measured ~30 us of the fused launch).  Offset of
+// (row, col) inside its 32 x 32 block; blocks follow each other [row tile][column tile].
+__device__ __forceinline__ int frag_off(int row, int col) { return ((col >> 3) * 64 + ((col >> 2) & 1) * 32 + row) * 4 + (col & 3); }
 // generic C/D map (A operand indexes rows): row (reg&3) + 8*(reg>>2) + 4*(lane>>5), column lane&31
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
@@ -224,17 +231,33 @@ __device__ __forceinline__ void split3(float x, u16& a, u16& b, u16& c)
     a = __builtin_bit_cast(u16, t0); b = __builtin_bit_cast(u16, t1); c = __builtin_bit_cast(u16, t2);
 }
 
+// the same split for two values at once, terms returned as packed bf16 pairs (x in the low half):
+// one v_cvt_pk_bf16_f32 per term, a shift and a mask to widen a pair back to fp32
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3x2(float x, float y, unsigned& a, unsigned& b, unsigned& c)
+{
+    f32x2 v = {x, y};
+    a = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    v[0] -= __builtin_bit_cast(float, a << 16);
+    v[1] -= __builtin_bit_cast(float, a & 0xffff0000u);
+    b = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    v[0] -= __builtin_bit_cast(float, b << 16);
+    v[1] -= __builtin_bit_cast(float, b & 0xffff0000u);
+    c = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
 // four consecutive columns of one row -> the three term planes of an LDS tile (8-byte stores)
 template <int K>
 __device__ __forceinline__ void store_split4(u16* lds_plane0, int row, int col, const float4& y)
 {
-    u16 a[4], b[4], c[4];
-    split3(y.x, a[0], b[0], c[0]); split3(y.y, a[1], b[1], c[1]);
-    split3(y.z, a[2], b[2], c[2]); split3(y.w, a[3], b[3], c[3]);
+    unsigned a0, b0, c0, a1, b1, c1;
+    split3x2(y.x, y.y, a0, b0, c0);
+    split3x2(y.z, y.w, a1, b1, c1);
     u16* q = lds_plane0 + row * (K + B3_PAD) + col;
-    *reinterpret_cast<uint2*>(q) = make_uint2(a[0] | ((unsigned)a[1] << 16), a[2] | ((unsigned)a[3] << 16));
-    *reinterpret_cast<uint2*>(q + b3_plane<K>()) = make_uint2(b[0] | ((unsigned)b[1] << 16), b[2] | ((unsigned)b[3] << 16));
-    *reinterpret_cast<uint2*>(q + 2 * b3_plane<K>()) = make_uint2(c[0] | ((unsigned)c[1] << 16), c[2] | ((unsigned)c[3] << 16));
+    *reinterpret_cast<uint2*>(q) = make_uint2(a0, a1);
+    *reinterpret_cast<uint2*>(q + b3_plane<K>()) = make_uint2(b0, b1);
+    *reinterpret_cast<uint2*>(q + 2 * b3_plane<K>()) = make_uint2(c0, c1);
 }
 
 // bias + ELU epilogue of the bf16x3 path: hi + lo, activation to HBM as fp32 (the backward and dW
@@ -256,9 +279,9 @@ __device__ __forceinline__ void epilogue_elu_b3(const f32x16& hi, const f32x16& 
         store_split4<N>(lds_plane0, r, nb, y[g]);
     }
     if (gtile != nullptr && r < nvalid) {
-        float* grow = gtile + r * NG + col0 + acc_n(0, lane);
+        float* gl = gtile + (col0 / 32) * 1024 + lane * 4;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(grow + 8 * g) = y[g];
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(gl + g * 256) = y[g];
     }
 }
 
@@ -286,11 +309,11 @@ __device__ __forceinline__ void epilogue_elu(const f32x16 (&acc)[NT], const floa
         }
     }
     if (gtile != nullptr && r < nvalid) {
-        float* grow = gtile + r * NG + col0 + acc_n(0, lane);
+        float* gl = gtile + (col0 / 32) * 1024 + lane * 4;        // column tile col0/32 of this row tile, fragment order
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(grow + 32 * t + 8 * g) = y[t][g];
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(gl + t * 1024 + g * 256) = y[t][g];
     }
 }
 
@@ -467,7 +490,7 @@ __device__ __forceinline__ void forward_body(
             stamp<STAMP>(stamps, 5);
             gemm_prefetch<MLP_H2, 1>(w2b, PF + MLP_OFF_F2 + MLP_H2 * (MLP_H1 / 2), wave, lane);
             __syncthreads();                                   // every wave has finished reading the first half of H1
-            epilogue_elu<MLP_H2, 1, MLP_H1>(acc, ldsBias + LB1 + MLP_H1 / 2, wave * 32, ldsA, lane, h1_tile ? h1_tile + MLP_H1 / 2 : nullptr, nvalid);
+            epilogue_elu<MLP_H2, 1, MLP_H1>(acc, ldsBias + LB1 + MLP_H1 / 2, wave * 32, ldsA, lane, h1_tile ? h1_tile + 4 * 1024 : nullptr, nvalid);
         }
         stamp<STAMP>(stamps, 6);
         __syncthreads();
@@ -524,7 +547,7 @@ __device__ __forceinline__ void forward_body(
             float y = (col < MLP_NACT) ? elu(z) : ((col == MLP_NACT) ? z : 0.0f);   // ELU on the mean (ppo.py:30), none on v
             const bool in = row < nvalid;
             if (in) {
-                if (out_save) (out_save + row0 * MLP_OUT)[i] = y;
+                if (out_save) (out_save + row0 * MLP_OUT)[frag_off(row, col)] = y;
                 if (mu_out && col < MLP_NACT) (mu_out + row0 * MLP_NACT)[row * MLP_NACT + col] = y;
                 if (v_out && col == MLP_NACT) (v_out + row0)[row] = y;
             }
@@ -559,7 +582,7 @@ __device__ __forceinline__ void forward_body(
 
 // bf16x3 variant of the forward body: same tile flow, activations live in LDS as three bf16 term planes
 constexpr int B3_TILE_FLOATS = 3 * b3_plane<MLP_H2>() / 2;        // a [32][128] tile as three planes, in floats
-constexpr int FWD_B3_LDS_FLOATS = 2 * B3_TILE_FLOATS + LDS_C_FLOATS;
+constexpr int FWD_B3_LDS_FLOATS = 2 * B3_TILE_FLOATS + LB4;      // two tiles + b1 | b2 | b3: 54 272 B, three workgroups per CU
 
 // The body walks tiles first_tile, first_tile + tile_stride, ... (< ntiles) on the caller's LDS
 // arena.
@@ -630,14 +653,16 @@ __device__ __forceinline__ void forward_body_b3(
         ldsBias[LB1 + tid] = P[MLP_OFF_B1 + tid];
         if (tid < MLP_H2) ldsBias[LB2 + tid] = P[MLP_OFF_B2 + tid];
         else ldsBias[LB3 + tid - MLP_H2] = P[MLP_OFF_B3 + tid - MLP_H2];
-        if (tid < MLP_OUT) ldsBias[LB4 + tid] = P[MLP_OFF_B4 + tid];
-        if (smp_var && tid >= 64 && tid < 64 + MLP_NACT) {
-            float v = smp_var[tid - 64];
-            for (int i = 0; i < smp_var_steps; ++i) v = fmaxf(smp_var_min, v - smp_var_decay);   // ppo.py:236-237, not yet applied to the tensor
-            const float L = sqrtf(v);
-            ldsBias[LSD + tid - 64] = L;
-            ldsBias[LLG + tid - 64] = logf(L);
-        }
+    }
+    // this thread's output column is the same in every tile: its layer-4 bias and sampling constants
+    // stay in registers (the LDS budget of this path is exactly three workgroups per CU)
+    const float b4v = P[MLP_OFF_B4 + (tid & 31)];
+    float smpL = 1.0f, smpLog = 0.0f;
+    if (smp_var && (tid & 31) < MLP_NACT) {
+        float v = smp_var[tid & 31];
+        for (int i = 0; i < smp_var_steps; ++i) v = fmaxf(smp_var_min, v - smp_var_decay);   // ppo.py:236-237, not yet applied to the tensor
+        smpL = sqrtf(v);
+        smpLog = logf(smpL);
     }
     for (; tile < ntiles; tile += tile_stride) {
         const long row0 = tile * BM;
@@ -697,7 +722,7 @@ __device__ __forceinline__ void forward_body_b3(
             stamp<STAMP>(stamps, 5);
             gemm_prefetch_b3<MLP_H2>(w2b, PB + MLP_OFF_PB2 + 3 * MLP_H2 * (MLP_H1 / 2), wave, lane);
             __syncthreads();                                   // every wave has finished reading the first half of H1
-            epilogue_elu_b3<MLP_H2, MLP_H1>(hi, lo, ldsBias + LB1 + MLP_H1 / 2, wave * 32, ldsA, lane, h1_tile ? h1_tile + MLP_H1 / 2 : nullptr, nvalid);
+            epilogue_elu_b3<MLP_H2, MLP_H1>(hi, lo, ldsBias + LB1 + MLP_H1 / 2, wave * 32, ldsA, lane, h1_tile ? h1_tile + 4 * 1024 : nullptr, nvalid);
         }
         stamp<STAMP>(stamps, 6);
         __syncthreads();
@@ -761,11 +786,11 @@ __device__ __forceinline__ void forward_body_b3(
             const int i = tl + k * THREADS;
             const int row = i >> 5, col = i & 31;
             float z = ((ldsBf[i] + ldsBf[BM * MLP_OUT + i]) + ldsBf[2 * BM * MLP_OUT + i]) + ldsBf[3 * BM * MLP_OUT + i];
-            z += ldsBias[LB4 + col];
+            z += b4v;
             float y = (col < MLP_NACT) ? elu(z) : ((col == MLP_NACT) ? z : 0.0f);   // ELU on the mean (ppo.py:30), none on v
             const bool in = row < nvalid;
             if (in) {
-                if (out_save) (out_save + row0 * MLP_OUT)[i] = y;
+                if (out_save) (out_save + row0 * MLP_OUT)[frag_off(row, col)] = y;
                 if (mu_out && col < MLP_NACT) (mu_out + row0 * MLP_NACT)[row * MLP_NACT + col] = y;
                 if (v_out && col == MLP_NACT) (v_out + row0)[row] = y;
             }
@@ -776,11 +801,11 @@ __device__ __forceinline__ void forward_body_b3(
                 float x2 = 0.0f, lg = 0.0f, a = 0.0f;
                 const bool on = (col < MLP_NACT) && in;
                 if (on) {
-                    const float L = ldsBias[LSD + col];
+                    const float L = smpL;
                     a = y + L * eps_pre[k];
                     const float xj = (a - y) / L;
                     x2 = xj * xj;
-                    lg = ldsBias[LLG + col];
+                    lg = smpLog;
                 }
 #pragma unroll
                 for (int o = 1; o < 32; o <<= 1) { x2 += __shfl_xor(x2, o, 32); lg += __shfl_xor(lg, o, 32); }
@@ -845,14 +870,15 @@ struct HFrag { float4 v[NT][4]; };
 template <int N, int NT>
 __device__ __forceinline__ void hfrag_load(HFrag<NT>& hf, const float* __restrict__ htile, int nvalid, int col0, int lane)
 {
-    // rows past the end of the batch read the last valid row instead: their results are never
-    // stored and a row of an MFMA only feeds the same row, so no predicate and no zero fill
-    const int r = min(lane & 31, nvalid - 1);
-    const float* hrow = htile + r * N + col0 + acc_n(0, lane);
+    // the saved activations are in tile-fragment order (see below): this wave's four loads of a
+    // column tile are four contiguous KiB.  Rows past the end of the batch read whatever the
+    // (allocated) rest of the last tile holds: their results are never stored and a row of an
+    // MFMA only feeds the same row.
+    const float* gl = htile + (col0 / 32) * 1024 + lane * 4;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) hf.v[t][g] = *reinterpret_cast<const float4*>(hrow + 32 * t + 8 * g);
+        for (int g = 0; g < 4; ++g) hf.v[t][g] = *reinterpret_cast<const float4*>(gl + t * 1024 + g * 256);
 }
 
 // writes dZ to the gradient rows in HBM and (lds_out != nullptr) to the LDS tile the next GEMM reads
@@ -876,11 +902,11 @@ __device__ __forceinline__ void epilogue_dact(const f32x16 (&acc)[NT], const HFr
         }
     }
     if (r < nvalid) {
-        float* grow = gtile + r * N + col0 + acc_n(0, lane);
+        float* gl = gtile + (col0 / 32) * 1024 + lane * 4;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(grow + 32 * t + 8 * g) = z[t][g];
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(gl + t * 1024 + g * 256) = z[t][g];
     }
 }
 
@@ -933,7 +959,7 @@ __device__ __forceinline__ void backward_body(
         for (int k = 0; k < BM * MLP_OUT / THREADS; ++k) {
             const int row = (tid >> 5) + k * (THREADS / 32);
             const bool in = row < nvalid;
-            const float y = in ? out_t[row * MLP_OUT + col] : 0.0f;                   // mean (cols 0..17), value (col 18)
+            const float y = in ? out_t[frag_off(row, col)] : 0.0f;                   // mean (cols 0..17), value (col 18)
             const float a = (in && act) ? act_t[row * MLP_NACT + col] : 0.0f;
             const float xj = act ? (a - y) / L : 0.0f;
             float M = xj * xj;
@@ -958,7 +984,7 @@ __device__ __forceinline__ void backward_body(
                 hub = fabsf(dv) < 1.0f ? 0.5f * dv * dv : fabsf(dv) - 0.5f;
                 if (act) d = c * (a - y) / var_col * elu_grad_from_out(y);
                 else if (col == MLP_NACT) d = inv_batch * fminf(fmaxf(dv, -1.0f), 1.0f);   // smooth_l1', beta = 1
-                dz4_t[row * MLP_OUT + col] = d;
+                dz4_t[frag_off(row, col)] = d;
             }
             ldsZ4[row * (MLP_OUT + 4) + col] = d;
             if (col == 0) { rowloss[2 * row] = pol; rowloss[2 * row + 1] = hub; }
@@ -1013,9 +1039,9 @@ __device__ __forceinline__ void epilogue_dact_b3(const f32x16& hi, const f32x16&
         if (lds_plane0) store_split4<N>(lds_plane0, r, col0 + acc_n(g, lane), z[g]);
     }
     if (r < nvalid) {
-        float* grow = gtile + r * N + col0 + acc_n(0, lane);
+        float* gl = gtile + (col0 / 32) * 1024 + lane * 4;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(grow + 8 * g) = z[g];
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(gl + g * 256) = z[g];
     }
 }
 
@@ -1064,7 +1090,7 @@ __device__ __forceinline__ void backward_body_b3(
         for (int k = 0; k < BM * MLP_OUT / THREADS; ++k) {
             const int row = (tid >> 5) + k * (THREADS / 32);
             const bool in = row < nvalid;
-            const float y = in ? out_t[row * MLP_OUT + col] : 0.0f;                   // mean (cols 0..17), value (col 18)
+            const float y = in ? out_t[frag_off(row, col)] : 0.0f;                   // mean (cols 0..17), value (col 18)
             const float a = (in && act) ? act_t[row * MLP_NACT + col] : 0.0f;
             const float xj = act ? (a - y) / L : 0.0f;
             float M = xj * xj;
@@ -1089,7 +1115,7 @@ __device__ __forceinline__ void backward_body_b3(
                 hub = fabsf(dv) < 1.0f ? 0.5f * dv * dv : fabsf(dv) - 0.5f;
                 if (act) d = c * (a - y) / var_col * elu_grad_from_out(y);
                 else if (col == MLP_NACT) d = inv_batch * fminf(fmaxf(dv, -1.0f), 1.0f);   // smooth_l1', beta = 1
-                dz4_t[row * MLP_OUT + col] = d;
+                dz4_t[frag_off(row, col)] = d;
             }
             {
                 u16 sa, sb, sc;
@@ -1197,7 +1223,7 @@ constexpr int FB_B3_LDS_FLOATS = FWD_B3_LDS_FLOATS > BW_B3_LDS_FLOATS ? FWD_B3_L
 
 // B3: the bf16x3 GEMM bodies (PF/PT then point at the 16-bit term planes PB/PTB)
 template <bool STAMP, bool B3>
-__global__ __launch_bounds__(THREADS, B3 ? 2 : WGS_PER_CU) void mlp_fwd_bwd_kernel(
+__global__ __launch_bounds__(THREADS, B3 ? 3 : WGS_PER_CU) void mlp_fwd_bwd_kernel(
     const float* __restrict__ P, const void* __restrict__ PF, const void* __restrict__ PT,
     const float* __restrict__ x, long n, float* __restrict__ out_save, float* __restrict__ h1_save,
     float* __restrict__ h2_save, float* __restrict__ h3_save,
@@ -1208,7 +1234,11 @@ __global__ __launch_bounds__(THREADS, B3 ? 2 : WGS_PER_CU) void mlp_fwd_bwd_kern
     unsigned long long* __restrict__ stamps)
 {
     __shared__ __attribute__((aligned(16))) float lds[B3 ? FB_B3_LDS_FLOATS : FB_LDS_FLOATS];
-    __shared__ int ok;
+    // bf16x3: the consumer's wait result lives in the arena's last word, past everything the backward
+    // body uses (a separate word would push the allocation over a third of the CU's LDS)
+    static_assert(FB_B3_LDS_FLOATS > BW_B3_LDS_FLOATS, "room for the flag word");
+    __shared__ int ok_word;
+    int& ok = B3 ? *reinterpret_cast<int*>(lds + FB_B3_LDS_FLOATS - 1) : ok_word;
     if (STAMP && threadIdx.x == 0) stamps[4L * blockIdx.x] = realtime_cu();
     const long tiles = (n + BM - 1) / BM;
     const long pad_tiles = (tiles + 7) & ~7L;              // consumers start at a multiple of 8: same XCD as their producer
@@ -1294,13 +1324,18 @@ __device__ void grad_w_layer(const GradWLayer& L, long nrows, int wg, float* lds
     constexpr int ZV = (GW_ROWS * N / 4 + GW_THREADS - 1) / GW_THREADS;          // float4 per thread
     constexpr int AV = A_VEC ? (GW_ROWS * KA / 4 + GW_THREADS - 1) / GW_THREADS
                              : (GW_ROWS * KA + GW_THREADS - 1) / GW_THREADS;     // float4 or float per thread
-    constexpr int BUF = GW_ROWS * (N + KPAD);
+    // LDS pitches: the tile-fragment source hands a wave 32 ROWS of one 4-column group per load, so
+    // the tiles it fills are padded by 4 floats (conflict-free 16-byte row-strided writes)
+    constexpr int ZP = N + 4, AP = A_VEC ? KPAD + 4 : KPAD;
+    constexpr int BUF = GW_ROWS * (ZP + AP);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR: weight bases become scalar
     const int r = lane & 31, h = lane >> 5;
     const bool active = wave < WN * WK;
     const int wn = active ? wave / WK : 0, wk = active ? wave % WK : 0;
-    const long rows_per = (nrows + L.wgs - 1) / L.wgs;
-    const long rbeg = (long)wg * rows_per;
+    // slabs are whole 32-row tiles (the saved tensors are stored tile by tile)
+    const long tiles = (nrows + GW_ROWS - 1) / GW_ROWS;
+    const long rows_per = ((tiles + L.wgs - 1) / L.wgs) * GW_ROWS;
+    const long rbeg = (long)wg * rows_per < nrows ? (long)wg * rows_per : nrows;
     const long rend = (rbeg + rows_per < nrows) ? rbeg + rows_per : nrows;
     const float* __restrict__ gz = L.dz;
     const float* __restrict__ ga = L.a;
@@ -1321,8 +1356,8 @@ __device__ void grad_w_layer(const GradWLayer& L, long nrows, int wg, float* lds
     auto load_chunk = [&](long c0) {
 #pragma unroll
         for (int v = 0; v < ZV; ++v) {
-            const int i = tid + v * GW_THREADS;                 // float4 index inside the chunk
-            const long g = c0 + (i * 4) / N;
+            const int i = tid + v * GW_THREADS;                 // float4 index inside the chunk = [column tile][g][lane]
+            const long g = c0 + (i & 31);                       // its row
             zreg[v] = (i < GW_ROWS * N / 4 && g < rend) ? *reinterpret_cast<const float4*>(gz + c0 * N + 4L * i)
                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -1330,7 +1365,7 @@ __device__ void grad_w_layer(const GradWLayer& L, long nrows, int wg, float* lds
 #pragma unroll
             for (int v = 0; v < AV; ++v) {
                 const int i = tid + v * GW_THREADS;
-                const long g = c0 + (i * 4) / KA;
+                const long g = c0 + (i & 31);
                 areg4[v] = (i < GW_ROWS * KA / 4 && g < rend) ? *reinterpret_cast<const float4*>(ga + c0 * KA + 4L * i)
                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -1345,20 +1380,21 @@ __device__ void grad_w_layer(const GradWLayer& L, long nrows, int wg, float* lds
     };
     auto store_chunk = [&](float* buf) {
         float* bz = buf;
-        float* ba = buf + GW_ROWS * N;
+        float* ba = buf + GW_ROWS * ZP;
+        // float4 index i of a tile-ordered chunk = [column tile i>>8][g (i>>6)&3][lane i&63]: row lane&31,
+        // columns 32*ct + 8*g + 4*(lane>>5) .. +3
 #pragma unroll
         for (int v = 0; v < ZV; ++v) {
             const int i = tid + v * GW_THREADS;
-            if (i < GW_ROWS * N / 4) *reinterpret_cast<float4*>(bz + 4 * i) = zreg[v];
+            if (i < GW_ROWS * N / 4)
+                *reinterpret_cast<float4*>(bz + (i & 31) * ZP + (i >> 8) * 32 + ((i >> 6) & 3) * 8 + ((i >> 5) & 1) * 4) = zreg[v];
         }
         if (A_VEC) {
 #pragma unroll
             for (int v = 0; v < AV; ++v) {
                 const int i = tid + v * GW_THREADS;
-                if (i < GW_ROWS * KA / 4) {
-                    const int rr = (4 * i) / KA, cc = (4 * i) - rr * KA;
-                    *reinterpret_cast<float4*>(ba + rr * KPAD + cc) = areg4[v];
-                }
+                if (i < GW_ROWS * KA / 4)
+                    *reinterpret_cast<float4*>(ba + (i & 31) * AP + (i >> 8) * 32 + ((i >> 6) & 3) * 8 + ((i >> 5) & 1) * 4) = areg4[v];
             }
         } else {
 #pragma unroll
@@ -1366,7 +1402,7 @@ __device__ void grad_w_layer(const GradWLayer& L, long nrows, int wg, float* lds
                 const int i = tid + v * GW_THREADS;
                 if (i < GW_ROWS * KA) {
                     const int rr = i / KA, cc = i - rr * KA;
-                    ba[rr * KPAD + cc] = areg1[v];
+                    ba[rr * AP + cc] = areg1[v];
                 }
             }
         }
@@ -1385,19 +1421,19 @@ __device__ void grad_w_layer(const GradWLayer& L, long nrows, int wg, float* lds
         const bool more = c0 + GW_ROWS < rend;
         if (more) load_chunk(c0 + GW_ROWS);                     // in flight during the MFMAs below
         const float* bz = lds + cur * BUF;
-        const float* ba = bz + GW_ROWS * N;
+        const float* ba = bz + GW_ROWS * ZP;
         {   // column sums of dZ (bias gradient): all threads take a slice of the 32 rows of one column
             constexpr int PARTS = (GW_THREADS / N) < 1 ? 1 : ((GW_THREADS / N) > GW_ROWS ? GW_ROWS : (GW_THREADS / N));
             constexpr int RPP = GW_ROWS / PARTS;
             const int colb = tid % N, part = tid / N;
             if (part < PARTS) {
 #pragma unroll
-                for (int rr = 0; rr < RPP; ++rr) bsum += bz[(part * RPP + rr) * N + colb];
+                for (int rr = 0; rr < RPP; ++rr) bsum += bz[(part * RPP + rr) * ZP + colb];
             }
         }
         if (active) {
-            const float* zp = bz + h * N + wn * (TNW * 32) + r;
-            const float* ap = ba + h * KPAD + wk * (TKW * 32) + r;
+            const float* zp = bz + h * ZP + wn * (TNW * 32) + r;
+            const float* ap = ba + h * AP + wk * (TKW * 32) + r;
             // operands of step st+1 are read from LDS before the MFMAs of step st are issued
             float zn[TNW], an[TKW];
 #pragma unroll
@@ -1413,9 +1449,9 @@ __device__ void grad_w_layer(const GradWLayer& L, long nrows, int wg, float* lds
                 for (int b = 0; b < TKW; ++b) av[b] = an[b];
                 if (st + 1 < GW_ROWS / 2) {
 #pragma unroll
-                    for (int a = 0; a < TNW; ++a) zn[a] = zp[2 * (st + 1) * N + 32 * a];
+                    for (int a = 0; a < TNW; ++a) zn[a] = zp[2 * (st + 1) * ZP + 32 * a];
 #pragma unroll
-                    for (int b = 0; b < TKW; ++b) an[b] = ap[2 * (st + 1) * KPAD + 32 * b];
+                    for (int b = 0; b < TKW; ++b) an[b] = ap[2 * (st + 1) * AP + 32 * b];
                 }
                 __builtin_amdgcn_sched_barrier(0);      // keep the prefetch reads ahead of this step's MFMAs
 #pragma unroll
@@ -1723,7 +1759,9 @@ extern "C" hipError_t flyhip_launch_mlp_backward_dx(const float* PT, const float
 }
 
 // workgroups per layer, proportional to the layer's share of the dW FLOPs (256 in total)
-static const int kGradWgs[4] = {72, 112, 56, 16};   // multiples of 8: every layer spreads evenly over the 8 XCDs
+// slabs are whole 32-row tiles: at 1280 tiles these counts give 16 / 12 / 24 / 86 tiles per workgroup, i.e. equal
+// work per workgroup across the layers (tiles x padded layer FLOPs: 393k / 393k / 393k / 352k)
+static const int kGradWgs[4] = {80, 107, 54, 15};
 
 extern "C" hipError_t flyhip_launch_mlp_fwd_bwd(const float* P, const float* PF, const float* PT, const float* x, int64_t n,
                                                 float* out_save, float* h1_save, float* h2_save, float* h3_save,
@@ -1789,10 +1827,9 @@ extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, 
         ws += (long)kGradWgs[l] * ((long)N[l] * KP[l] + N[l]);
         first += kGradWgs[l];
     }
-    // dynamic LDS: the largest layer's staging tiles: max over layers of 32*(N + TK*32) floats
-    // dynamic LDS: two buffers of the largest layer's chunk: 2 x 32 x (128 + 256) floats = 96 KiB
-    const size_t lds_bytes = sizeof(float) * 2 * GW_ROWS * (MLP_H2 + MLP_H1);
-    static_assert(MLP_H1 + 96 <= MLP_H2 + MLP_H1, "layer 1 chunk fits");
+    // dynamic LDS: two buffers of the largest layer's chunk (pitches padded by 4): 2 x 32 x (132 + 260) floats = 98 KiB
+    const size_t lds_bytes = sizeof(float) * 2 * GW_ROWS * (MLP_H2 + 4 + MLP_H1 + 4);
+    static_assert(MLP_H1 + 4 + 96 <= MLP_H2 + 4 + MLP_H1 + 4, "layer 1 chunk fits");
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_grad_w_kernel),

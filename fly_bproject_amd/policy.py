@@ -99,6 +99,17 @@ def build_plane_maps():
     return idx_fb, idx_tb
 
 
+def untile(t, n, N):
+    """[rows][N] view of a saved activation / dZ buffer, which the kernels keep in tile-fragment order
+    (csrc/mlp_mfma.hip, frag_off): per 32-row tile and 32-column tile a block of 1024 floats
+    [g][lane][4] with lane = 32 * ((col % 8) // 4) + row % 32, g = (col % 32) // 8."""
+    rows = torch.arange(n, device=t.device).view(-1, 1)
+    cols = torch.arange(N, device=t.device).view(1, -1)
+    c = cols % 32
+    off = ((rows // 32) * (N // 32) + cols // 32) * 1024 + ((c // 8) * 64 + ((c // 4) % 2) * 32 + rows % 32) * 4 + c % 4
+    return t.reshape(-1)[off]
+
+
 def split_bf16x3(w):
     """fp32 tensor -> three int16 tensors holding the bf16 terms w0 + w1 + w2 == w (exact)."""
     w0 = w.to(torch.bfloat16)
@@ -215,7 +226,7 @@ class PackedPolicy:
         self.grad_norm = self._norm_ws[:1]
         self.workspace = torch.empty(int(self._lib.mlp_grad_workspace_floats()), device=dev)
         self.max_rows = int(max_rows)
-        r = self.max_rows
+        r = (self.max_rows + 31) // 32 * 32        # whole 32-row tiles: the saved tensors are stored tile by tile
         self.saves = {"out": torch.empty(r, OUT, device=dev), "h1": torch.empty(r, H1, device=dev),
                       "h2": torch.empty(r, H2, device=dev), "h3": torch.empty(r, H3, device=dev)}
         self.dz = {"dz4": torch.empty(r, OUT, device=dev), "dz3": torch.empty(r, H3, device=dev),

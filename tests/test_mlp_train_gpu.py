@@ -193,8 +193,10 @@ def test_one_launch_forward_backward_equals_two_launches(n):
             t.fill_(float("nan"))
         pol.minibatch_grad(x, action, old_logp, adv, target, var, 0.2)
         torch.cuda.synchronize()
-        got = [pol.saves[k][:n].clone() for k in ("out", "h1", "h2", "h3")] + \
-              [pol.dz[k][:n].clone() for k in ("dz4", "dz3", "dz2", "dz1")] + \
+        from fly_bproject_amd.policy import untile
+        width = {"out": 32, "h1": 256, "h2": 128, "h3": 128, "dz4": 32, "dz3": 128, "dz2": 128, "dz1": 256}
+        got = [untile(pol.saves[k], n, width[k]) for k in ("out", "h1", "h2", "h3")] + \
+              [untile(pol.dz[k], n, width[k]) for k in ("dz4", "dz3", "dz2", "dz1")] + \
               [pol.loss_part[: (n + 31) // 32].clone(), pol.G.clone()]
         assert all(torch.isfinite(t).all() for t in got)
         if fuse:
@@ -209,7 +211,7 @@ def test_bf16x3_training_step_matches_fp32_path():
     """One minibatch gradient + Adam step with the bf16x3 GEMMs (forward, dX chain; dW stays on fp32
     MFMA) against the fp32-MFMA path and torch autograd: same loss and gradients to the suite's fp32
     tolerance, and the bf16 term planes the Adam kernel scatters equal a fresh split of the weights."""
-    from fly_bproject_amd.policy import split_bf16x3
+    from fly_bproject_amd.policy import split_bf16x3, untile
     n = 4099
     net, ref, pol, (x, action, old_logp, adv, target, var) = _setup(n, 21)
     res = {}
@@ -219,7 +221,7 @@ def test_bf16x3_training_step_matches_fp32_path():
             pol.fuse_fwd_bwd = fuse
             pol.minibatch_grad(x, action, old_logp, adv, target, var, 0.2)
             torch.cuda.synchronize()
-            res[(mode, fuse)] = (pol.G.clone(), float(pol.loss_value(n)), pol.dz["dz1"][:n].clone())
+            res[(mode, fuse)] = (pol.G.clone(), float(pol.loss_value(n)), untile(pol.dz["dz1"], n, 256))
     assert torch.equal(res[("bf16x3", False)][0], res[("bf16x3", True)][0])       # one launch == two launches, bit for bit
     g32, l32, z32 = res[("f32", True)]
     g3, l3, z3 = res[("bf16x3", True)]

@@ -95,11 +95,13 @@ def test_mfma_forward_matches_torch_and_oracle(golden, n):
         with torch.no_grad():
             h1 = ref.shared_net[1](ref.shared_net[0](x)); h2 = ref.shared_net(x)
             h3 = torch.cat([ref.to_mean[1](ref.to_mean[0](h2)), ref.to_value[1](ref.to_value[0](h2))], dim=1)
-        torch.testing.assert_close(saves["h1"], h1, rtol=2e-5, atol=2e-5)
-        torch.testing.assert_close(saves["h2"], h2, rtol=2e-5, atol=2e-5)
-        torch.testing.assert_close(saves["h3"], h3, rtol=2e-5, atol=2e-5)
-        torch.testing.assert_close(saves["out"][:, :18], mu_t, rtol=2e-5, atol=2e-5)
-        assert torch.all(saves["out"][:, 19:] == 0)
+        from fly_bproject_amd.policy import untile          # saved tensors are in tile-fragment order
+        torch.testing.assert_close(untile(saves["h1"], n, 256), h1, rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(untile(saves["h2"], n, 128), h2, rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(untile(saves["h3"], n, 128), h3, rtol=2e-5, atol=2e-5)
+        out_rows = untile(saves["out"], n, 32)
+        torch.testing.assert_close(out_rows[:, :18], mu_t, rtol=2e-5, atol=2e-5)
+        assert torch.all(out_rows[:, 19:] == 0)
         # determinism
         mu2 = net.pi(x) if not torch.is_grad_enabled() else None
         with torch.no_grad():
@@ -244,7 +246,7 @@ def test_bf16x3_forward_is_fp32_accurate(n):
     """The bf16x3 GEMM path (three-term bf16 split of both operands, six MFMA terms, fp32 accumulate)
     against an fp64 evaluation of the same network: its error must stay within the fp32 tolerance of
     this suite (2e-5) and within 2x of the error of the fp32-MFMA path on the same inputs."""
-    from fly_bproject_amd.policy import PackedPolicy
+    from fly_bproject_amd.policy import PackedPolicy, untile
     from fly_bproject_amd.ppo import Net
     torch.manual_seed(n + 1)
     net = Net(73, 18).to("cuda:0")
@@ -264,7 +266,7 @@ def test_bf16x3_forward_is_fp32_accurate(n):
             mu, v = pol.forward(x, saves=pol.saves)
         torch.cuda.synchronize()
         err[mode] = (float((mu.double() - mu64).abs().max()), float((v.double() - v64).abs().max()),
-                     float((pol.saves["h1"][:n].double() - h1_64).abs().max()))
+                     float((untile(pol.saves["h1"], n, 256).double() - h1_64).abs().max()))
         assert torch.isfinite(mu).all() and torch.isfinite(v).all()
     for a, b in zip(err["bf16x3"], err["f32"]):
         assert a <= 2e-5 and a <= 2.0 * b + 1e-7, err
