@@ -20,6 +20,8 @@
 // split-over-rows kernel (see below).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdio>
+#include <cstdlib>
 #include "flyhip.h"
 #include "mlp_layout.h"
 
@@ -1308,6 +1310,9 @@ struct GradWLayer {
 };
 struct GradWTable { GradWLayer l[4]; };
 
+#ifndef GW_PAD
+#define GW_PAD 4
+#endif
 constexpr int GW_ROWS = 32;      // rows staged per chunk (16 MFMA k-steps)
 constexpr int GW_THREADS = 1024; // 16 waves: 4 per SIMD, so a wave's LDS/barrier stalls hide behind three others
 
@@ -1325,8 +1330,8 @@ __device__ void grad_w_layer(const GradWLayer& L, long nrows, int wg, float* lds
     constexpr int AV = A_VEC ? (GW_ROWS * KA / 4 + GW_THREADS - 1) / GW_THREADS
                              : (GW_ROWS * KA + GW_THREADS - 1) / GW_THREADS;     // float4 or float per thread
     // LDS pitches: the tile-fragment source hands a wave 32 ROWS of one 4-column group per load, so
-    // the tiles it fills are padded by 4 floats (conflict-free 16-byte row-strided writes)
-    constexpr int ZP = N + 4, AP = A_VEC ? KPAD + 4 : KPAD;
+    // the tiles it fills are padded (a row's two 16-byte pieces, lanes r and r + 32, then land 8 banks past the previous row's)
+    constexpr int ZP = N + GW_PAD, AP = A_VEC ? KPAD + GW_PAD : KPAD;
     constexpr int BUF = GW_ROWS * (ZP + AP);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR: weight bases become scalar
     const int r = lane & 31, h = lane >> 5;
@@ -1353,6 +1358,21 @@ __device__ void grad_w_layer(const GradWLayer& L, long nrows, int wg, float* lds
     float4 areg4[A_VEC ? AV : 1];
     float areg1[A_VEC ? 1 : AV];
 
+    // tile-ordered float4 index i = [column tile i>>8][g (i>>6)&3][lane i&63] -> LDS offset of (row lane&31,
+    // columns 32*ct + 8*g + 4*(lane>>5)); fixed per thread, computed once
+    int zoff[ZV], aoff[A_VEC ? AV : 1];
+#pragma unroll
+    for (int v = 0; v < ZV; ++v) {
+        const int i = tid + v * GW_THREADS;
+        zoff[v] = (i & 31) * ZP + (i >> 8) * 32 + ((i >> 6) & 3) * 8 + ((i >> 5) & 1) * 4;
+    }
+    if (A_VEC) {
+#pragma unroll
+        for (int v = 0; v < AV; ++v) {
+            const int i = tid + v * GW_THREADS;
+            aoff[v] = (i & 31) * AP + (i >> 8) * 32 + ((i >> 6) & 3) * 8 + ((i >> 5) & 1) * 4;
+        }
+    }
     auto load_chunk = [&](long c0) {
 #pragma unroll
         for (int v = 0; v < ZV; ++v) {
@@ -1386,15 +1406,13 @@ __device__ void grad_w_layer(const GradWLayer& L, long nrows, int wg, float* lds
 #pragma unroll
         for (int v = 0; v < ZV; ++v) {
             const int i = tid + v * GW_THREADS;
-            if (i < GW_ROWS * N / 4)
-                *reinterpret_cast<float4*>(bz + (i & 31) * ZP + (i >> 8) * 32 + ((i >> 6) & 3) * 8 + ((i >> 5) & 1) * 4) = zreg[v];
+            if (i < GW_ROWS * N / 4) *reinterpret_cast<float4*>(bz + zoff[v]) = zreg[v];
         }
         if (A_VEC) {
 #pragma unroll
             for (int v = 0; v < AV; ++v) {
                 const int i = tid + v * GW_THREADS;
-                if (i < GW_ROWS * KA / 4)
-                    *reinterpret_cast<float4*>(ba + (i & 31) * AP + (i >> 8) * 32 + ((i >> 6) & 3) * 8 + ((i >> 5) & 1) * 4) = areg4[v];
+                if (i < GW_ROWS * KA / 4) *reinterpret_cast<float4*>(ba + aoff[v]) = areg4[v];
             }
         } else {
 #pragma unroll
@@ -1759,9 +1777,20 @@ extern "C" hipError_t flyhip_launch_mlp_backward_dx(const float* PT, const float
 }
 
 // workgroups per layer, proportional to the layer's share of the dW FLOPs (256 in total)
-// slabs are whole 32-row tiles: at 1280 tiles these counts give 16 / 12 / 24 / 86 tiles per workgroup, i.e. equal
-// work per workgroup across the layers (tiles x padded layer FLOPs: 393k / 393k / 393k / 352k)
-static const int kGradWgs[4] = {80, 107, 54, 15};
+// slabs are whole 32-row tiles; a chunk costs its MFMAs plus a fixed staging/barrier overhead, so the thin layers
+// (3 and 4) get more workgroups than their FLOP share: measured best of a dozen splits at 1280 tiles
+static int kGradWgs[4] = {80, 100, 52, 24};
+static bool gw_env_read = false;
+static void gw_read_env()
+{   // tuning aid: FLYHIP_GW_SPLIT="a,b,c,d" overrides the split (sum <= 256)
+    if (gw_env_read) return;
+    gw_env_read = true;
+    const char* e = getenv("FLYHIP_GW_SPLIT");
+    int v[4];
+    if (e && sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0 &&
+        v[0] + v[1] + v[2] + v[3] <= 1024)
+        for (int i = 0; i < 4; ++i) kGradWgs[i] = v[i];
+}
 
 extern "C" hipError_t flyhip_launch_mlp_fwd_bwd(const float* P, const float* PF, const float* PT, const float* x, int64_t n,
                                                 float* out_save, float* h1_save, float* h2_save, float* h3_save,
@@ -1804,6 +1833,7 @@ extern "C" int flyhip_debug_mlp_fwd_bwd_stamped(const float* P, const float* PF,
 
 extern "C" int64_t flyhip_mlp_grad_workspace_floats(void)
 {
+    gw_read_env();
     return (int64_t)kGradWgs[0] * MLP_H1 * (MLP_IN_PAD + 1) + (int64_t)kGradWgs[1] * MLP_H2 * (MLP_H1 + 1) +
            (int64_t)kGradWgs[2] * MLP_H3 * (MLP_H2 + 1) + (int64_t)kGradWgs[3] * MLP_OUT * (MLP_H3 + 1);   // N*KP + N per slab
 }
@@ -1813,6 +1843,7 @@ extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, 
                                                int64_t n, float* workspace, float* grad_out, const float* norm_mask,
                                                float* norm_ws, int* norm_step, void* stream)
 {
+    gw_read_env();
     GradWTable T;
     const float* dz[4] = {dz1, dz2, dz3, dz4};
     const float* a[4] = {x, h1, h2, h3};
@@ -1827,9 +1858,9 @@ extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, 
         ws += (long)kGradWgs[l] * ((long)N[l] * KP[l] + N[l]);
         first += kGradWgs[l];
     }
-    // dynamic LDS: two buffers of the largest layer's chunk (pitches padded by 4): 2 x 32 x (132 + 260) floats = 98 KiB
-    const size_t lds_bytes = sizeof(float) * 2 * GW_ROWS * (MLP_H2 + 4 + MLP_H1 + 4);
-    static_assert(MLP_H1 + 4 + 96 <= MLP_H2 + 4 + MLP_H1 + 4, "layer 1 chunk fits");
+    // dynamic LDS: two buffers of the largest layer's chunk (padded pitches): 2 x 32 x (136 + 264) floats = 100 KiB
+    const size_t lds_bytes = sizeof(float) * 2 * GW_ROWS * (MLP_H2 + GW_PAD + MLP_H1 + GW_PAD);
+    static_assert(MLP_H1 + GW_PAD + 96 <= MLP_H2 + GW_PAD + MLP_H1 + GW_PAD, "layer 1 chunk fits");
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_grad_w_kernel),

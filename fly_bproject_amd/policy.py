@@ -129,7 +129,8 @@ class PackedPolicy:
         # GEMM arithmetic of the MFMA kernels: "f32" = v_mfma_f32_32x32x2_f32, "bf16x3" = three-term bf16
         # split of both operands on v_mfma_f32_32x32x16_bf16 (fp32-accurate, see csrc/mlp_layout.h)
         self.gemm = os.environ.get("FLY_GEMM", "f32")
-        assert self.gemm in ("f32", "bf16x3")
+        self.gemm_infer = os.environ.get("FLY_GEMM_INFER", "f32")
+        assert self.gemm in ("f32", "bf16x3") and self.gemm_infer in ("f32", "bf16x3")
         self.PB = torch.zeros(PB_HALVES, dtype=torch.int16, device=self.device)
         self.PTB = torch.zeros(PTB_HALVES, dtype=torch.int16, device=self.device)
         idx_fb, idx_tb = build_plane_maps()
@@ -193,7 +194,13 @@ class PackedPolicy:
     version = 0         # bumped whenever the weights change: consumers of cached network outputs compare it
 
     def pb_ptr(self):
+        """Term planes for the UPDATE's forward (minibatch_grad); inference launches (rollout policy,
+        critic rows, Net.pi / Net.v) stay on the fp32 MFMA body, which at one tile per CU is bound by
+        latency, not by matrix time."""
         return C.c_void_p(self.PB.data_ptr()) if self.gemm == "bf16x3" else None
+
+    def infer_pb_ptr(self):
+        return C.c_void_p(self.PB.data_ptr()) if self.gemm_infer == "bf16x3" else None
 
     def ptb_ptr(self):
         return C.c_void_p(self.PTB.data_ptr()) if self.gemm == "bf16x3" else None
@@ -210,7 +217,8 @@ class PackedPolicy:
         s = saves or {}
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
         _lib.check(self._lib.mlp_forward(ptr(self.P), ptr(self.PF), ptr(x2), C.c_int64(n), ptr(mu), ptr(v), ptr(s.get("out")),
-                                         ptr(s.get("h1")), ptr(s.get("h2")), ptr(s.get("h3")), self.pb_ptr(), _lib.stream_ptr()),
+                                         ptr(s.get("h1")), ptr(s.get("h2")), ptr(s.get("h3")),
+                                         self.pb_ptr() if saves else self.infer_pb_ptr(), _lib.stream_ptr()),
                    "mlp_forward")
         return (mu.view(*lead, NACT) if want_mu else None), (v.view(*lead, 1) if want_v else None)
 

@@ -326,7 +326,7 @@ class PPO:
             fwd.append((P(pol.P.data_ptr()), P(pol.PF.data_ptr()), P(self._obs_rows[t].data_ptr()), C.c_int64(n),
                         P(self._eps_all[t].data_ptr()), var_ptr, self._var_steps, C.c_float(self._var_decay), self._var_min,
                         P(self._act_rows[t].data_ptr()), P(self.all_log_prob[t].data_ptr()), None,
-                        P(self._v_ring[t].data_ptr()), pol.pb_ptr()))
+                        P(self._v_ring[t].data_ptr()), pol.infer_pb_ptr()))
             book.append((P(self._reward_rows[t].data_ptr()), C.c_int64(n), P(self._score_acc.data_ptr()),
                          C.c_float(1.0 / self.num_eval_freq), var_ptr, C.c_int(self.num_acts)))
             bufs.append((self._obs_rows[t + 1].data_ptr(), self._reward_rows[t].data_ptr()))

@@ -179,7 +179,7 @@ def test_fused_forward_sample_matches_separate_kernels(n):
     _lib.check(lib.ppo_sample_logprob(p(mu), p(var), p(eps), p(act1), p(lp1), n, None), "sample")
     act2 = torch.empty(n, 18, device="cuda:0"); lp2 = torch.empty(n, device="cuda:0"); mu2 = torch.empty(n, 18, device="cuda:0")
     v2 = torch.empty(n, device="cuda:0")
-    _lib.check(lib.mlp_forward_sample(p(pol.P), p(pol.PF), p(x), n, p(eps), p(var), 0, 0.0, 0.0, p(act2), p(lp2), p(mu2), p(v2), pol.pb_ptr(), None), "fused")
+    _lib.check(lib.mlp_forward_sample(p(pol.P), p(pol.PF), p(x), n, p(eps), p(var), 0, 0.0, 0.0, p(act2), p(lp2), p(mu2), p(v2), pol.infer_pb_ptr(), None), "fused")
     torch.cuda.synchronize()
     assert torch.equal(mu, mu2) and torch.equal(act1, act2) and torch.equal(v1.view(-1), v2)
     torch.testing.assert_close(lp1, lp2, rtol=2e-6, atol=1e-5)
