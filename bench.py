@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1, help="PPO iterations untimed")
     ap.add_argument("--num_envs", type=int, default=8192, help="envs per GPU")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_alt_gemm", action="store_true", help="skip the secondary bf16x3 measurement")
     ap.add_argument("--kernel_reps", type=int, default=200)
     return ap.parse_args()
 
@@ -68,7 +69,7 @@ def _time_launches(fn, reps):
 MLP_FWD_FLOP = 2 * (73 * 256 + 256 * 128 + 128 * 64 * 2 + 64 * 18 + 64)        # 138 112
 MLP_BWD_DX_FLOP = 2 * (64 * 18 + 64 + 128 * 128 + 128 * 256)                   # 100 736
 MLP_GRAD_W_FLOP = MLP_FWD_FLOP
-PEAK_HBM_GBS, PEAK_F32_MFMA_TFLOPS = 8000.0, 157.3                             # MI355X_MICROARCH.md
+PEAK_HBM_GBS, PEAK_F32_MFMA_TFLOPS, PEAK_BF16_MFMA_TFLOPS = 8000.0, 157.3, 2500.0                             # MI355X_MICROARCH.md
 
 
 def kernel_rooflines(num_envs, T, reps):
@@ -126,17 +127,19 @@ def kernel_rooflines(num_envs, T, reps):
                 "algorithmic_per_launch": bytes_per_launch, "launches_per_iteration": per_iter,
                 "iteration_share_ms": round(dur * per_iter * 1e3, 3)}
 
-    def mfma(name, dur, flop_per_launch, per_iter):
+    def mfma(name, dur, flop_per_launch, per_iter, peak=PEAK_F32_MFMA_TFLOPS):
         ach = flop_per_launch / dur / 1e12
-        return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5), "traffic": None,
+        return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(ach / peak, 5), "traffic": None,
                 "avg_launch_us": round(dur * 1e6, 3), "algorithmic_per_launch": flop_per_launch,
                 "launches_per_iteration": per_iter, "iteration_share_ms": round(dur * per_iter * 1e3, 3)}
 
     ks = [
         hbm("fly_kernel<63> (fly_step)", t_step, FUSED_STEP_BYTES_PER_ENV * num_envs, T),
         # the update's forward + loss + dX chain of one 40 960-row minibatch is ONE launch
-        mfma("mlp_fwd_bwd_kernel", t_fb, (MLP_FWD_FLOP + MLP_BWD_DX_FLOP) * rows, 75),
+        # bf16x3 mode: six bf16 MFMA terms per product, so the algorithmic-FLOP roofline is the dense bf16 peak / 6
+        mfma("mlp_fwd_bwd_kernel", t_fb, (MLP_FWD_FLOP + MLP_BWD_DX_FLOP) * rows, 75,
+             PEAK_F32_MFMA_TFLOPS if pol.gemm == "f32" else round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)),
         # rollout policy + sampling (+ v(obs_t)) of num_envs rows, and once per iteration v(last next_obs)
         mfma("mlp_forward_kernel (policy + sample, %d rows)" % num_envs, t_pol, MLP_FWD_FLOP * num_envs, T + 1),
         mfma("mlp_grad_w_kernel (+reduce)", t_gw, MLP_GRAD_W_FLOP * rows, 75),
@@ -270,6 +273,30 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, rollout_s = float(tt[0]), float(tt[1])
     assert agent.optim_step == 75 * (a.warmup + a.steps), agent.optim_step
+    # Secondary, clearly labelled measurement: the same iteration with the update's forward + dX GEMMs
+    # on the bf16 matrix pipe through three-term operand splits (fp32-accurate: tools/bf16x3_gemm.hip,
+    # tests/test_mlp_train_gpu.py::test_bf16x3_training_step_matches_fp32_path).  `value` above is the
+    # default fp32-MFMA path.
+    alt = None
+    main_gemm = agent.policy.gemm
+    if main_gemm == "f32" and not a.no_alt_gemm:
+        agent.policy.gemm = "bf16x3"
+        iteration()
+        fence()
+        a0 = time.perf_counter()
+        for _ in range(2):
+            iteration()
+        fence()
+        alt_s = time.perf_counter() - a0
+        if world > 1:
+            tt = torch.tensor([alt_s], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            alt_s = float(tt[0])
+        alt = {"gemm": "bf16x3 (three-term bf16 split of both operands, six product terms, fp32 accumulate) for the update's "
+                       "forward and dX chain; dW, inference and everything else unchanged",
+               "value": round(world * a.num_envs * T * 2 / alt_s, 1), "unit": "env-steps/s", "steps": 2,
+               "ms_per_step": round(alt_s / 2 * 1e3, 3)}
+        agent.policy.gemm = main_gemm
     finite = all(torch.isfinite(p).all().item() for p in agent.net.parameters())
     ep_ret, ep_len, ep_cnt = agent.env.episode_stats()
     agent.exit()
@@ -282,16 +309,19 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if main_gemm == "f32" else "f32 via bf16x3 operand splits (update forward + dX), fp32 accumulate",
+            "data": "synthetic",
             "config": {"workload": "fly_ppo_iteration_%denvs_T%d" % (a.num_envs, T),
                        "num_envs_per_gpu": a.num_envs, "rollout_size": T, "optimizer_steps_per_iteration": 75,
                        "minibatch_samples": agent.mini_chunk_size * a.num_envs, "variant": "bigGrav",
-                       "parallelism": "dp%d" % world},
+                       "parallelism": "dp%d" % world, "gemm": main_gemm},
             "rollout_only_env_steps_per_s": round(world * a.num_envs * T / rollout_s, 1),
             "params_finite": finite,
             "mean_episode_return": None if ep_cnt == 0 else round(ep_ret, 4),
             "mean_episode_length": None if ep_cnt == 0 else round(ep_len, 2), "episodes_finished": ep_cnt,
         }
+        if alt:
+            line["bf16x3_update"] = alt
         ks = kernel_rooflines(a.num_envs, T, a.kernel_reps)
         line["roofline"] = ks[0]                     # the dominant kernel of one iteration
         line["kernels"] = ks[1:]
