@@ -206,7 +206,10 @@ int ppo_rollout_bookkeeping(const float* reward, int64_t rows, int64_t n, float*
  * Every output pointer is optional (NULL):
  *   mu_out [n][18]  actor mean (after its ELU)        v_out [n]  critic value
  *   out_save [n][32], h1_save [n][256], h2_save [n][128], h3_save [n][128]: activations kept
- *   for the backward pass.
+ *   for the backward pass.  These (and the dz* tensors below) are kernel-to-kernel scratch in
+ *   TILE-FRAGMENT order, not row-major: per 32-row tile and 32-column tile one block of 1024
+ *   floats [register group g][lane][4] with lane = 32*((col%8)/4) + row%32, g = (col%32)/8,
+ *   blocks ordered [row tile][column tile]; allocate ceil32(n) rows.
  * GEMM arithmetic: with params_b3 = NULL the layers run on v_mfma_f32_32x32x2_f32 (fp32 products,
  * fp32 accumulate).  With params_b3 = the weights as three bf16 terms each (w = w0 + w1 + w2 exactly,
  * MLP_PB_HALVES_ABI 16-bit words, layout in mlp_layout.h; mlp_adam_step maintains it) the same GEMMs
