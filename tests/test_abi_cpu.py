@@ -71,3 +71,32 @@ def test_fly_fails_loudly_without_gpu():
         args.sim_device = "cuda:0"
         with pytest.raises(_lib.FlyHipError):
             Fly(args)
+
+
+def test_bf16x3_planes_and_tile_layout_maps():
+    """Host-side layout logic of the bf16x3 path and of the tile-fragment saved tensors: the plane
+    index maps are injective and cover the buffers exactly, the three-term split is exact, and
+    `untile` inverts the kernels' frag_off formula."""
+    import numpy as np
+    import torch
+    from fly_bproject_amd import policy as P
+    idx_fb, idx_tb = P.build_plane_maps()
+    for idx, size in ((idx_fb, P.PB_HALVES), (idx_tb, P.PTB_HALVES)):
+        used = idx[idx >= 0].astype(np.int64)
+        allpos = np.concatenate([used, used + 512, used + 1024])
+        assert len(np.unique(allpos)) == len(allpos) == size and allpos.max() == size - 1
+    # layer-1 bias rows and padding columns have no plane copy; every real weight has one
+    assert (idx_fb >= 0).sum() == 256 * 80 + 128 * 256 + 128 * 128 + 32 * 128
+    torch.manual_seed(0)
+    w = torch.randn(4096) * torch.logspace(-6, 3, 4096)
+    terms = [t.view(torch.bfloat16).float() for t in P.split_bf16x3(w)]
+    assert torch.equal(terms[0] + terms[1] + terms[2], w)            # exact: 3 x 8 mantissa bits
+    # untile: fill a buffer through the documented formula and read it back row-major
+    n, N = 70, 128
+    rows, cols = np.meshgrid(np.arange(n), np.arange(N), indexing="ij")
+    c = cols % 32
+    off = ((rows // 32) * (N // 32) + cols // 32) * 1024 + ((c // 8) * 64 + ((c // 4) % 2) * 32 + rows % 32) * 4 + c % 4
+    buf = torch.full((((n + 31) // 32) * 32 * N,), float("nan"))
+    buf[torch.from_numpy(off.reshape(-1))] = torch.arange(n * N, dtype=torch.float32)
+    assert torch.equal(P.untile(buf, n, N), torch.arange(n * N, dtype=torch.float32).view(n, N))
+    assert len(np.unique(off)) == n * N
