@@ -28,6 +28,8 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// 16-byte store of a register group to a saved tensor (nontemporal stores measured 4-6 % slower)
+#define GSTORE4(ptr, v) (*reinterpret_cast<float4*>(ptr) = (v))
 
 constexpr int BM = 32;          // rows per workgroup
 constexpr int NWAVE = 4;
@@ -283,7 +285,7 @@ __device__ __forceinline__ void epilogue_elu_b3(const f32x16& hi, const f32x16& 
     if (gtile != nullptr && r < nvalid) {
         float* gl = gtile + (col0 / 32) * 1024 + lane * 4;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(gl + g * 256) = y[g];
+        for (int g = 0; g < 4; ++g) GSTORE4(gl + g * 256, y[g]);
     }
 }
 
@@ -315,7 +317,7 @@ __device__ __forceinline__ void epilogue_elu(const f32x16 (&acc)[NT], const floa
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(gl + t * 1024 + g * 256) = y[t][g];
+            for (int g = 0; g < 4; ++g) GSTORE4(gl + t * 1024 + g * 256, y[t][g]);
     }
 }
 
@@ -908,7 +910,7 @@ __device__ __forceinline__ void epilogue_dact(const f32x16 (&acc)[NT], const HFr
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(gl + t * 1024 + g * 256) = z[t][g];
+            for (int g = 0; g < 4; ++g) GSTORE4(gl + t * 1024 + g * 256, z[t][g]);
     }
 }
 
@@ -1043,7 +1045,7 @@ __device__ __forceinline__ void epilogue_dact_b3(const f32x16& hi, const f32x16&
     if (r < nvalid) {
         float* gl = gtile + (col0 / 32) * 1024 + lane * 4;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(gl + g * 256) = z[g];
+        for (int g = 0; g < 4; ++g) GSTORE4(gl + g * 256, z[g]);
     }
 }
 
