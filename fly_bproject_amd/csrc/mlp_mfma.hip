@@ -321,15 +321,6 @@ __device__ __forceinline__ void epilogue_elu(const f32x16 (&acc)[NT], const floa
     }
 }
 
-template <int NT>
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NT])
-{
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-}
-
 // Both tile kernels fit four workgroups per CU: <= 40 KB of LDS and <= 128 VGPRs each.
 constexpr int WGS_PER_CU = 4;
 constexpr int PERSIST_GRID = 256 * WGS_PER_CU;       // persistent launches: every slot of the chip
