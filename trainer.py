@@ -36,6 +36,9 @@ def parse_args(argv=None):
     parser.add_argument('--reward', type=str, default="standing", choices=["standing", "walking"])
     parser.add_argument('--max_steps', type=int, default=0, help='stop after this many env steps (0 = run until env.end)')
     parser.add_argument('--seed', type=int, default=0)
+    parser.add_argument('--gemm', type=str, default=None, choices=["f32", "bf16x3"],
+                        help='arithmetic of the update\'s forward/dX GEMMs: fp32 MFMA (default) or three-term bf16 operand '
+                             'splits on the bf16 matrix pipe (fp32-accurate, DESIGN.md 3.4); default: $FLY_GEMM or f32')
     parser.add_argument('--dp_mode', type=str, default="grad_allreduce", choices=["grad_allreduce", "param_average"],
                         help='multi-GPU: all-reduce the gradient every optimizer step (reference algorithm on the global '
                              'batch) or average parameters once per PPO update (non-parity)')
@@ -65,6 +68,8 @@ def main(argv=None):
     if args.testing:
         print("## Careful you are in testing mode, no Training will take place ##")
     policy = PPO(args)                      # trainer.py:39
+    if args.gemm:
+        policy.policy.gemm = args.gemm
     broadcast_policy(policy)
     end = False                             # trainer.py:41-44
     while not end:
