@@ -40,6 +40,9 @@ constexpr int THREADS = 64 * NWAVE;
 __device__ __forceinline__ float elu(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
 // derivative of ELU expressed through its OUTPUT y: 1 for y > 0, y + 1 otherwise
 __device__ __forceinline__ float elu_grad_from_out(float y) { return y > 0.0f ? 1.0f : y + 1.0f; }
+// dA * ELU'(H) with H the saved OUTPUT: ELU' = min(H, 0) + 1, so the product is one min and one fma
+// (dA * min(H, 0) + dA, rounded once) instead of compare, select, add, multiply
+__device__ __forceinline__ float dact(float da, float h) { return fmaf(da, fminf(h, 0.0f), da); }
 
 // acc[t] (+)= W[col tile t][K] * A[32 rows x K]^T for this wave's NT column tiles.  The WEIGHTS are
 // the MFMA "A" operand and the activations the "B" operand, so the 32x32 result tile is
@@ -889,10 +892,10 @@ __device__ __forceinline__ void epilogue_dact(const f32x16 (&acc)[NT], const HFr
         for (int g = 0; g < 4; ++g) {
             const int nb = col0 + 32 * t + acc_n(g, lane);
             const float4 hv = hf.v[t][g];
-            z[t][g].x = acc[t][4 * g + 0] * elu_grad_from_out(hv.x);
-            z[t][g].y = acc[t][4 * g + 1] * elu_grad_from_out(hv.y);
-            z[t][g].z = acc[t][4 * g + 2] * elu_grad_from_out(hv.z);
-            z[t][g].w = acc[t][4 * g + 3] * elu_grad_from_out(hv.w);
+            z[t][g].x = dact(acc[t][4 * g + 0], hv.x);
+            z[t][g].y = dact(acc[t][4 * g + 1], hv.y);
+            z[t][g].z = dact(acc[t][4 * g + 2], hv.z);
+            z[t][g].w = dact(acc[t][4 * g + 3], hv.w);
             if (lds_out) *reinterpret_cast<float4*>(lds_out + r * (N + 4) + nb) = z[t][g];
         }
     }
@@ -1027,10 +1030,10 @@ __device__ __forceinline__ void epilogue_dact_b3(const f32x16& hi, const f32x16&
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const float4 hv = hf.v[0][g];
-        z[g].x = (hi[4 * g + 0] + lo[4 * g + 0]) * elu_grad_from_out(hv.x);
-        z[g].y = (hi[4 * g + 1] + lo[4 * g + 1]) * elu_grad_from_out(hv.y);
-        z[g].z = (hi[4 * g + 2] + lo[4 * g + 2]) * elu_grad_from_out(hv.z);
-        z[g].w = (hi[4 * g + 3] + lo[4 * g + 3]) * elu_grad_from_out(hv.w);
+        z[g].x = dact(hi[4 * g + 0] + lo[4 * g + 0], hv.x);
+        z[g].y = dact(hi[4 * g + 1] + lo[4 * g + 1], hv.y);
+        z[g].z = dact(hi[4 * g + 2] + lo[4 * g + 2], hv.z);
+        z[g].w = dact(hi[4 * g + 3] + lo[4 * g + 3], hv.w);
         if (lds_plane0) store_split4<N>(lds_plane0, r, col0 + acc_n(g, lane), z[g]);
     }
     if (r < nvalid) {
