@@ -836,7 +836,7 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_forward_kernel(
                         smp_var_min);
 }
 
-__global__ __launch_bounds__(THREADS, 2) void mlp_forward_b3_kernel(
+__global__ __launch_bounds__(THREADS, 1) void mlp_forward_b3_kernel(
     const float* __restrict__ P, const u16* __restrict__ PB, const float* __restrict__ x, long n,
     float* __restrict__ mu_out, float* __restrict__ v_out, float* __restrict__ out_save,
     float* __restrict__ h1_save, float* __restrict__ h2_save, float* __restrict__ h3_save,
@@ -844,7 +844,9 @@ __global__ __launch_bounds__(THREADS, 2) void mlp_forward_b3_kernel(
     float* __restrict__ smp_logp, int smp_var_steps, float smp_var_decay, float smp_var_min)
 {
     __shared__ __attribute__((aligned(16))) float lds[FWD_B3_LDS_FLOATS];
-    forward_body_b3<false>(lds, blockIdx.x, gridDim.x, P, PB, x, n, mu_out, v_out, out_save, h1_save, h2_save, h3_save,
+    // one tile per workgroup (a constant stride no tile index reaches): this body's straight-line GEMMs
+    // leave no registers for the next-tile prefetch of the persistent fp32 variant
+    forward_body_b3<false>(lds, blockIdx.x, 1L << 40, P, PB, x, n, mu_out, v_out, out_save, h1_save, h2_save, h3_save,
                            smp_eps, smp_var, smp_act, smp_logp, nullptr, smp_var_steps, smp_var_decay, smp_var_min);
 }
 
@@ -1699,7 +1701,7 @@ extern "C" hipError_t flyhip_launch_mlp_forward(const float* P, const float* PF,
 {
     if (PB) {       // bf16x3 GEMMs
         const long tiles = (n + BM - 1) / BM;
-        const int grid = (int)(tiles <= 4 * 512 ? tiles : 512);
+        const int grid = (int)tiles;
         hipLaunchKernelGGL(mlp_forward_b3_kernel, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PB, x, (long)n, mu_out,
                            v_out, out_save, h1_save, h2_save, h3_save, (const float*)nullptr, (const float*)nullptr,
                            (float*)nullptr, (float*)nullptr, 0, 0.0f, 0.0f);
@@ -1725,7 +1727,7 @@ extern "C" hipError_t flyhip_launch_mlp_forward_sample(const float* P, const flo
 {
     if (PB) {
         const long tiles = (n + BM - 1) / BM;
-        const int grid = (int)(tiles <= 4 * 512 ? tiles : 512);
+        const int grid = (int)tiles;
         hipLaunchKernelGGL(mlp_forward_b3_kernel, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PB, x, (long)n, mu_out,
                            v_out, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, eps, var, act_out,
                            logp_out, var_steps, var_decay, var_min);

@@ -128,9 +128,9 @@ class PackedPolicy:
         self.PT = torch.zeros(FRAG_T, dtype=torch.float32, device=self.device)    # W^T operands, fragment order
         # GEMM arithmetic of the MFMA kernels: "f32" = v_mfma_f32_32x32x2_f32, "bf16x3" = three-term bf16
         # split of both operands on v_mfma_f32_32x32x16_bf16 (fp32-accurate, see csrc/mlp_layout.h)
-        self.gemm = os.environ.get("FLY_GEMM", "f32")
+        self._gemm = os.environ.get("FLY_GEMM", "f32")
         self.gemm_infer = os.environ.get("FLY_GEMM_INFER", "f32")
-        assert self.gemm in ("f32", "bf16x3") and self.gemm_infer in ("f32", "bf16x3")
+        assert self._gemm in ("f32", "bf16x3") and self.gemm_infer in ("f32", "bf16x3")
         self.PB = torch.zeros(PB_HALVES, dtype=torch.int16, device=self.device)
         self.PTB = torch.zeros(PTB_HALVES, dtype=torch.int16, device=self.device)
         idx_fb, idx_tb = build_plane_maps()
@@ -185,13 +185,40 @@ class PackedPolicy:
         with torch.no_grad():
             self.PF[self._dst_f] = self.P[self._src_f]
             self.PT[self._dst_t] = self.P[self._src_t]
-            for dst_buf, src, dst in ((self.PB, self._src_fb, self._dst_fb), (self.PTB, self._src_tb, self._dst_tb)):
-                for term, plane in enumerate(split_bf16x3(self.P[src])):
-                    dst_buf[dst + 512 * term] = plane
+            self._refresh_planes()
         self.version += 1
 
     refresh_transposes = refresh
+
+    def _refresh_planes(self):
+        with torch.no_grad():
+            for dst_buf, src, dst in ((self.PB, self._src_fb, self._dst_fb), (self.PTB, self._src_tb, self._dst_tb)):
+                for term, plane in enumerate(split_bf16x3(self.P[src])):
+                    dst_buf[dst + 512 * term] = plane
+
+    def _planes_live(self):
+        return self._gemm == "bf16x3" or self.gemm_infer == "bf16x3"
+
+    @property
+    def gemm(self):
+        return self._gemm
+
+    @gemm.setter
+    def gemm(self, mode):
+        """Switching to bf16x3 rebuilds the term planes: the Adam kernel only maintains them while a
+        bf16x3 mode is active (six extra scattered stores per weight otherwise wasted)."""
+        assert mode in ("f32", "bf16x3")
+        was_live = self._planes_live()
+        self._gemm = mode
+        if self._planes_live() and not was_live:
+            self._refresh_planes()
     version = 0         # bumped whenever the weights change: consumers of cached network outputs compare it
+
+    def _plane_args(self):
+        if not self._planes_live():
+            return (None, None, None, None)
+        p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+        return (p(self.PB), p(self.PTB), p(self.idx_fb), p(self.idx_tb))
 
     def pb_ptr(self):
         """Term planes for the UPDATE's forward (minibatch_grad); inference launches (rollout policy,
@@ -317,5 +344,5 @@ class PackedPolicy:
                                            p(self.exp_avg_sq), p(self.step), C.c_float(self.lr),
                                            C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
                                            C.c_float(self.max_norm), C.c_float(grad_scale), p(self._norm_ws),
-                                           C.c_int(1 if norm_ready else 0), p(self.PB), p(self.PTB), p(self.idx_fb),
-                                           p(self.idx_tb), _lib.stream_ptr()), "mlp_adam_step")
+                                           C.c_int(1 if norm_ready else 0), *self._plane_args(), _lib.stream_ptr()),
+                   "mlp_adam_step")
