@@ -951,7 +951,7 @@ __device__ __forceinline__ void backward_body(
         const int col = tid & 31;
         const bool act = col < MLP_NACT;
         const float L = act ? sqrtf(var[col]) : 1.0f;
-        const float var_col = act ? var[col] : 1.0f;
+        const float inv_L = 1.0f / L, inv_var = act ? 1.0f / var[col] : 0.0f;       // one division each per thread, not per element
         float half_log_det = act ? logf(L) : 0.0f;
 #pragma unroll
         for (int o = 1; o < 32; o <<= 1) half_log_det += __shfl_xor(half_log_det, o, 32);
@@ -961,7 +961,7 @@ __device__ __forceinline__ void backward_body(
             const bool in = row < nvalid;
             const float y = in ? out_t[frag_off(row, col)] : 0.0f;                   // mean (cols 0..17), value (col 18)
             const float a = (in && act) ? act_t[row * MLP_NACT + col] : 0.0f;
-            const float xj = act ? (a - y) / L : 0.0f;
+            const float xj = act ? (a - y) * inv_L : 0.0f;
             float M = xj * xj;
 #pragma unroll
             for (int o = 1; o < 32; o <<= 1) M += __shfl_xor(M, o, 32);
@@ -982,7 +982,7 @@ __device__ __forceinline__ void backward_body(
                 pol = -fminf(s1, s2);
                 const float dv = __shfl(y, MLP_NACT, 32) - tgt_t[row];
                 hub = fabsf(dv) < 1.0f ? 0.5f * dv * dv : fabsf(dv) - 0.5f;
-                if (act) d = c * (a - y) / var_col * elu_grad_from_out(y);
+                if (act) d = c * (a - y) * inv_var * elu_grad_from_out(y);
                 else if (col == MLP_NACT) d = inv_batch * fminf(fmaxf(dv, -1.0f), 1.0f);   // smooth_l1', beta = 1
                 dz4_t[frag_off(row, col)] = d;
             }
@@ -1082,7 +1082,7 @@ __device__ __forceinline__ void backward_body_b3(
         const int col = tid & 31;
         const bool act = col < MLP_NACT;
         const float L = act ? sqrtf(var[col]) : 1.0f;
-        const float var_col = act ? var[col] : 1.0f;
+        const float inv_L = 1.0f / L, inv_var = act ? 1.0f / var[col] : 0.0f;       // one division each per thread, not per element
         float half_log_det = act ? logf(L) : 0.0f;
 #pragma unroll
         for (int o = 1; o < 32; o <<= 1) half_log_det += __shfl_xor(half_log_det, o, 32);
@@ -1092,7 +1092,7 @@ __device__ __forceinline__ void backward_body_b3(
             const bool in = row < nvalid;
             const float y = in ? out_t[frag_off(row, col)] : 0.0f;                   // mean (cols 0..17), value (col 18)
             const float a = (in && act) ? act_t[row * MLP_NACT + col] : 0.0f;
-            const float xj = act ? (a - y) / L : 0.0f;
+            const float xj = act ? (a - y) * inv_L : 0.0f;
             float M = xj * xj;
 #pragma unroll
             for (int o = 1; o < 32; o <<= 1) M += __shfl_xor(M, o, 32);
@@ -1113,7 +1113,7 @@ __device__ __forceinline__ void backward_body_b3(
                 pol = -fminf(s1, s2);
                 const float dv = __shfl(y, MLP_NACT, 32) - tgt_t[row];
                 hub = fabsf(dv) < 1.0f ? 0.5f * dv * dv : fabsf(dv) - 0.5f;
-                if (act) d = c * (a - y) / var_col * elu_grad_from_out(y);
+                if (act) d = c * (a - y) * inv_var * elu_grad_from_out(y);
                 else if (col == MLP_NACT) d = inv_batch * fminf(fmaxf(dv, -1.0f), 1.0f);   // smooth_l1', beta = 1
                 dz4_t[frag_off(row, col)] = d;
             }
@@ -1644,7 +1644,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void mlp_adam_apply_kernel(float* __r
                                                                       const int* __restrict__ idx_fb,
                                                                       const int* __restrict__ idx_tb)
 {
-    __shared__ float s_coef;
+    __shared__ float s_coef, s_step_size, s_bc2_sqrt;
     __shared__ float red[16];
     const int tid = threadIdx.x;
     {   // every block re-adds the same partial sums in the same order: identical clip coefficient
@@ -1662,16 +1662,19 @@ __global__ __launch_bounds__(ADAM_THREADS) void mlp_adam_apply_kernel(float* __r
         const float coef = max_norm / (norm + 1e-6f);          // torch.nn.utils.clip_grad_norm_
         s_coef = coef < 1.0f ? coef : 1.0f;
         if (blockIdx.x == 0) norm_ws[0] = norm;
+        // bias corrections of torch.optim.Adam, once per workgroup (two powf per thread otherwise)
+        const float ts = (float)*step;
+        const float bc1 = 1.0f - powf(beta1, ts);
+        const float bc2 = 1.0f - powf(beta2, ts);
+        s_step_size = lr / bc1;
+        s_bc2_sqrt = sqrtf(bc2);
     }
     __syncthreads();
     const int i = blockIdx.x * ADAM_THREADS + tid;
     if (i >= MLP_PACKED_FLOATS) return;
     const float coef = s_coef * grad_scale;
-    const int t = *step;
-    const float bc1 = 1.0f - powf(beta1, (float)t);
-    const float bc2 = 1.0f - powf(beta2, (float)t);
-    const float step_size = lr / bc1;
-    const float bc2_sqrt = sqrtf(bc2);
+    const float step_size = s_step_size;
+    const float bc2_sqrt = s_bc2_sqrt;
     const float mk = mask[i];
     const float g = G[i] * coef * mk;
     const float mi = beta1 * m[i] + (1.0f - beta1) * g;
