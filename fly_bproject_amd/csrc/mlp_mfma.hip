@@ -65,7 +65,13 @@ __device__ __forceinline__ float dact(float da, float h) { return fmaf(da, fminf
 // The first two weight k-quads of a GEMM are requested AHEAD of it: a caller issues `gemm_prefetch`
 // before the previous layer's epilogue / barrier so the L2 round trip (1-2 k cycles, once per layer
 // per tile) hides under that work instead of opening every MFMA run.
-constexpr int RING = 4, HEAD = 2, ARING = 2;      // weight sets (L2 latency), head sets, activation sets (LDS latency)
+#ifndef TUNE_RING
+#define TUNE_RING 4
+#endif
+#ifndef TUNE_ARING
+#define TUNE_ARING 2
+#endif
+constexpr int RING = TUNE_RING, HEAD = 2, ARING = TUNE_ARING;      // weight sets (L2 latency), head sets, activation sets (LDS latency)
 template <int NT>
 struct WeightHead { float4 b[HEAD][NT]; };
 
