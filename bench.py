@@ -157,6 +157,7 @@ def kernel_rooflines(num_envs, T, reps):
         traffic = {}
     grids = {"fly_kernel<63> (fly_step)": ("fly_kernel<63>", ((num_envs + 31) // 32) * 256),
              "mlp_fwd_bwd_kernel": ("mlp_fwd_bwd_kernel", 2 * ((rows + 31) // 32) * 256),
+             "mlp_forward_kernel (policy + sample, %d rows)" % num_envs: ("mlp_forward_kernel", ((num_envs + 31) // 32) * 256),
              "mlp_grad_w_kernel (+reduce)": ("mlp_grad_w_kernel", 256 * 1024)}
     for k in ks:
         key = grids.get(k["kernel"])
