@@ -248,6 +248,8 @@ class PPO:
     def update(self):
         """ppo.py:173-202: 5 epochs x 15 contiguous-in-T minibatches; the 16th chunk is never
         visited (Q3).  With world_size > 1 the flat gradient is all-reduced (mean) before the clip."""
+        if getattr(self, "_book_terms", None) is not None:
+            self._flush_bookkeeping()                               # the loss uses the variance after this rollout's decays
         obs, action, old_log_prob, target, advantage = self.make_data()
         if self.update_backend == "hip":
             return self._update_hip(obs, action, old_log_prob, target, advantage)
