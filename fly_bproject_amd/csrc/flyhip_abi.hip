@@ -64,6 +64,10 @@ extern "C" hipError_t flyhip_launch_mlp_fwd_bwd(const float* P, const float* PF,
 extern "C" hipError_t flyhip_launch_rollout_bookkeeping(const float* reward, int64_t rows, int64_t n, float* terms,
                                                         float* score_acc, float score_scale, float* action_var, int nvar,
                                                         float var_decay, float var_min, void* stream);
+extern "C" hipError_t flyhip_launch_rollout_step(const FlyConfig* dcfg, const FlyBuffers* b, const float* P, const float* PF,
+                                                 const float* x, int64_t n, const float* eps, const float* var, int var_steps,
+                                                 float var_decay, float var_min, float* act, float* logp, float* v_out,
+                                                 void* stream);
 extern "C" hipError_t flyhip_launch_adv_stats(const float* adv, int64_t n, float* stats, void* stream);
 extern "C" hipError_t flyhip_launch_adv_apply(float* adv, int64_t n, const float* totals, float count, float eps, void* stream);
 
@@ -128,7 +132,7 @@ int launch(FlyHandle h, int phases, const float* actions, const FlyBuffers* b, v
 extern "C" {
 
 const char* fly_last_error(void) { return g_err; }
-int fly_abi_version(void) { return 4; }
+int fly_abi_version(void) { return 5; }
 
 int fly_create(const FlyConfig* cfg, FlyHandle* out)
 {
@@ -166,6 +170,22 @@ int fly_destroy(FlyHandle h)
 int fly_step(FlyHandle h, const float* actions, const FlyBuffers* b, void* stream)
 {
     return launch(h, PH_SCALE | PH_RESET | PH_INTEGRATE | PH_OBS | PH_PROGRESS | PH_REWARD, actions, b, stream);
+}
+
+int ppo_rollout_step(FlyHandle h, const FlyBuffers* b, const float* params, const float* params_frag, const float* x,
+                     const float* eps, const float* var, int32_t var_steps, float var_decay, float var_min,
+                     float* act_out, float* logp_out, float* v_out, void* stream)
+{
+    if (!h) return fail(FLY_E_ARG, "handle is null");
+    if (!params || !params_frag || !x || !eps || !var || !act_out || !logp_out)
+        return fail(FLY_E_ARG, "ppo_rollout_step: null pointer");
+    if (var_steps < 0 || var_steps > (1 << 20)) return fail(FLY_E_ARG, "ppo_rollout_step: var_steps out of range");
+    int rc = check_buffers(b, PH_SCALE | PH_RESET | PH_INTEGRATE | PH_OBS | PH_PROGRESS | PH_REWARD);
+    if (rc) return rc;
+    hipError_t e = flyhip_launch_rollout_step(h->dev, b, params, params_frag, x, h->host.num_envs, eps, var, var_steps,
+                                              var_decay, var_min, act_out, logp_out, v_out, stream);
+    if (e != hipSuccess) return hip_fail(e, "ppo_rollout_step launch");
+    return FLY_OK;
 }
 
 int fly_scale_actions(FlyHandle h, const float* actions, float* targets, void* stream)

@@ -32,6 +32,30 @@ namespace {
 #include "mlp_backward.inc"
 #include "mlp_grad_w.inc"
 #include "mlp_adam.inc"
+#include "fly_body.inc"
+
+// One launch per env step of the rollout (ppo.py:213-230): workgroup b runs the policy forward +
+// sampling for the 32 envs of tile b (writing their action / log-prob / value rows) and then the
+// fused env step of exactly those envs (fly.py:624-681) -- the env body has the same 256-thread,
+// 32-env shape.  The actions go through HBM rows the workgroup itself just wrote (it waits for its
+// stores and re-reads them: same CU, and nothing has read those lines since the kernel began).
+// Bit for bit what mlp_forward_sample followed by fly_step leave.
+constexpr int RS_LDS_FLOATS = FWD_LDS_FLOATS > ENVS_PER_BLOCK * FLY_NUM_OBS ? FWD_LDS_FLOATS : ENVS_PER_BLOCK * FLY_NUM_OBS;
+static_assert(ENVS_PER_BLOCK == BM && BLOCK == THREADS, "one forward tile = one env block");
+
+__global__ __launch_bounds__(THREADS, 2) void rollout_step_kernel(
+    const FlyConfig* __restrict__ c, FlyBuffers b, const float* __restrict__ P, const float* __restrict__ PF,
+    const float* __restrict__ x, long n, const float* __restrict__ eps, const float* __restrict__ var, int var_steps,
+    float var_decay, float var_min, float* __restrict__ act, float* __restrict__ logp, float* __restrict__ v_out)
+{
+    __shared__ __attribute__((aligned(16))) float lds[RS_LDS_FLOATS];
+    forward_body<false>(lds, blockIdx.x, 1L << 40, P, PF, x, n, nullptr, v_out, nullptr, nullptr, nullptr, nullptr, eps, var, act,
+                        logp, nullptr, var_steps, var_decay, var_min);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);          // this thread's action stores are acknowledged by L2
+    __syncthreads();
+    fly_body<PH_SCALE | PH_RESET | PH_INTEGRATE | PH_OBS | PH_PROGRESS | PH_REWARD>(c, act, b, lds, blockIdx.x);
+}
 
 }  // namespace
 
@@ -167,6 +191,16 @@ extern "C" int flyhip_debug_mlp_fwd_bwd_stamped(const float* P, const float* PF,
                        (const void*)PF, (const void*)PT, x, (long)n, out_save, h1_save, h2_save, h3_save, action, old_logp, adv, target, var, inv_batch,
                        clip, dz4, dz3, dz2, dz1, loss_part, flags, epoch, err, stamps);
     return (int)hipGetLastError();
+}
+
+extern "C" hipError_t flyhip_launch_rollout_step(const FlyConfig* dcfg, const FlyBuffers* b, const float* P, const float* PF,
+                                                 const float* x, int64_t n, const float* eps, const float* var, int var_steps,
+                                                 float var_decay, float var_min, float* act, float* logp, float* v_out,
+                                                 void* stream)
+{
+    hipLaunchKernelGGL(rollout_step_kernel, dim3((unsigned)((n + BM - 1) / BM)), dim3(THREADS), 0, (hipStream_t)stream, dcfg, *b,
+                       P, PF, x, (long)n, eps, var, var_steps, var_decay, var_min, act, logp, v_out);
+    return hipGetLastError();
 }
 
 extern "C" int64_t flyhip_mlp_grad_workspace_floats(void)

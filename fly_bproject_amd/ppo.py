@@ -21,6 +21,7 @@ What changed underneath (MI355X-first, not a translation):
   * data-parallel training: one packed-gradient all-reduce over RCCL per optimizer step.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -317,7 +318,7 @@ class PPO:
         self._obs_rows = [self._obs_ring[t] for t in range(T + 1)]
         self._reward_rows = [self.all_reward[t].view(-1) for t in range(T)]
         self._act_rows = [self.all_acts[t] for t in range(T)]
-        fwd, book, bufs = [], [], []
+        fwd, book, bufs, step = [], [], [], []
         self._var_decay = 0.0 if self.args.testing else 0.00001     # ppo.py:236
         self._var_min = C.c_float(0.01)
         self._var_steps = C.c_int(0)                                 # pending decays, set before every policy launch
@@ -329,10 +330,16 @@ class PPO:
                         P(self._eps_all[t].data_ptr()), var_ptr, self._var_steps, C.c_float(self._var_decay), self._var_min,
                         P(self._act_rows[t].data_ptr()), P(self.all_log_prob[t].data_ptr()), None,
                         P(self._v_ring[t].data_ptr()), pol.infer_pb_ptr()))
+            step.append((P(pol.P.data_ptr()), P(pol.PF.data_ptr()), P(self._obs_rows[t].data_ptr()),
+                         P(self._eps_all[t].data_ptr()), var_ptr, self._var_steps, C.c_float(self._var_decay), self._var_min,
+                         P(self._act_rows[t].data_ptr()), P(self.all_log_prob[t].data_ptr()), P(self._v_ring[t].data_ptr())))
             book.append((P(self._reward_rows[t].data_ptr()), C.c_int64(n), P(self._score_acc.data_ptr()),
                          C.c_float(1.0 / self.num_eval_freq), var_ptr, C.c_int(self.num_acts)))
             bufs.append((self._obs_rows[t + 1].data_ptr(), self._reward_rows[t].data_ptr()))
-        self._fwd_args, self._book_args, self._buf_ptrs = fwd, book, bufs
+        self._fwd_args, self._book_args, self._buf_ptrs, self._step_args = fwd, book, bufs, step
+        # one launch per env step unless captured graphs or a bf16x3 inference body are asked for
+        self.fuse_rollout_step = (os.environ.get("FLY_FUSE_ROLLOUT_STEP", "1") != "0" and not self.use_graph
+                                  and pol.infer_pb_ptr() is None)
 
     def _launch_step(self, t):
         """The device work of one env step (ppo.py:213-237): two launches, no host logic.  Rows of
@@ -345,14 +352,18 @@ class PPO:
         if t == 0:
             self._rows_done = self._book_from = 0
         self._var_steps.value = (t - self._book_from) if self._lazy_book else 0
-        rc = lib.mlp_forward_sample(*self._fwd_args[t], st)         # ppo.py:214-220, :227 (policy + sampling fused)
+        env.obs_buf, env.reward_buf = self._obs_rows[t + 1], self._reward_rows[t]      # ppo.py:228-229
+        env._bufs.obs, env._bufs.reward = self._buf_ptrs[t]
+        if self.fuse_rollout_step:
+            # policy + sampling + env step of every 32-env tile in ONE launch (ppo.py:214-229)
+            rc = lib.ppo_rollout_step(env._handle, C.byref(env._bufs), *self._step_args[t], st)
+        else:
+            rc = lib.mlp_forward_sample(*self._fwd_args[t], st)     # ppo.py:214-220, :227 (policy + sampling fused)
+            rc |= lib.fly_step(env._handle, C.c_void_p(self._act_rows[t].data_ptr()), C.byref(env._bufs), st)  # ppo.py:223
         if t == 0:
             self._v_have, self._v_version = 1, self.policy.version
         elif self._v_have == t:
             self._v_have = t + 1
-        env.obs_buf, env.reward_buf = self._obs_rows[t + 1], self._reward_rows[t]      # ppo.py:228-229
-        env._bufs.obs, env._bufs.reward = self._buf_ptrs[t]
-        rc |= lib.fly_step(env._handle, C.c_void_p(self._act_rows[t].data_ptr()), C.byref(env._bufs), st)  # ppo.py:223
         # ppo.py:230 (all_done): see the property.  ppo.py:233 + :236-237: deferred, or one tiny launch
         if self._lazy_book:
             self._rows_done = t + 1

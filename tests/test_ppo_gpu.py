@@ -270,3 +270,25 @@ def test_bf16x3_forward_is_fp32_accurate(n):
         assert torch.isfinite(mu).all() and torch.isfinite(v).all()
     for a, b in zip(err["bf16x3"], err["f32"]):
         assert a <= 2e-5 and a <= 2.0 * b + 1e-7, err
+
+
+def test_one_launch_rollout_step_equals_two_launches():
+    """ppo_rollout_step (policy + sampling + env step of each 32-env tile in one launch) leaves bit for
+    bit what mlp_forward_sample followed by fly_step leave, over a whole rollout plus the next one."""
+    from fly_bproject_amd.ppo import PPO
+    res = {}
+    for fuse in (True, False):
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            agent = PPO(make_args(4096, testing=True))
+            agent.run()
+            assert agent.fuse_rollout_step
+            agent.fuse_rollout_step = fuse
+            _run(agent, agent.rollout_size + 6)
+        torch.cuda.synchronize()
+        res[fuse] = (agent._obs_ring.clone(), agent.all_acts.clone(), agent.all_reward.clone(), agent.all_log_prob.clone(),
+                     agent._v_ring.clone(), agent.env.progress_buf.clone(), agent.env.reset_buf.clone(),
+                     agent.env.root_tensor.clone(), agent.env.dof_states.clone())
+        agent.exit()
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
