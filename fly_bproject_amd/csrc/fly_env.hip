@@ -34,7 +34,9 @@ __global__ __launch_bounds__(BLOCK) void fly_kernel(const FlyConfig* __restrict_
                                                     const float* __restrict__ actions, FlyBuffers b)
 {
     __shared__ __attribute__((aligned(16))) float obs_tile[ENVS_PER_BLOCK * FLY_NUM_OBS];
-    fly_body<PH>(c, actions, b, obs_tile, blockIdx.x);
+    FlyRegs st;
+    fly_load<PH>(st, c, b, blockIdx.x);
+    fly_body<PH>(c, actions, b, obs_tile, blockIdx.x, st);
 }
 
 inline int grid_for(int n) { return (n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK; }

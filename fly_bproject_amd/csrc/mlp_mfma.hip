@@ -49,12 +49,15 @@ __global__ __launch_bounds__(THREADS, 2) void rollout_step_kernel(
     float var_decay, float var_min, float* __restrict__ act, float* __restrict__ logp, float* __restrict__ v_out)
 {
     __shared__ __attribute__((aligned(16))) float lds[RS_LDS_FLOATS];
+    constexpr int PH_ALL = PH_SCALE | PH_RESET | PH_INTEGRATE | PH_OBS | PH_PROGRESS | PH_REWARD;
+    FlyRegs st;
+    fly_load<PH_ALL>(st, c, b, blockIdx.x);                 // the env state's HBM round trip hides under the forward
     forward_body<false>(lds, blockIdx.x, 1L << 40, P, PF, x, n, nullptr, v_out, nullptr, nullptr, nullptr, nullptr, eps, var, act,
                         logp, nullptr, var_steps, var_decay, var_min);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);          // this thread's action stores are acknowledged by L2
     __syncthreads();
-    fly_body<PH_SCALE | PH_RESET | PH_INTEGRATE | PH_OBS | PH_PROGRESS | PH_REWARD>(c, act, b, lds, blockIdx.x);
+    fly_body<PH_ALL>(c, act, b, lds, blockIdx.x, st);
 }
 
 }  // namespace
