@@ -84,7 +84,6 @@ def kernel_rooflines(num_envs, T, reps):
     env = Fly(make_args(num_envs))
     a = torch.zeros(num_envs, 18, device="cuda:0").uniform_(-1, 1)
     t_step = _time_launches(lambda: env.step(a), reps)
-    env.exit()
     rows = (40960 // num_envs) * num_envs
     net = Net(73, 18).to("cuda:0")
     pol = PackedPolicy(net, "cuda:0")
@@ -115,6 +114,10 @@ def kernel_rooflines(num_envs, T, reps):
     v_o = torch.empty(num_envs, device="cuda:0")
     t_pol = _time_launches(lambda: lib.mlp_forward_sample(p(pol.P), p(pol.PF), p(xs), num_envs, p(eps), p(var), 0, 0.0, 0.0, p(a_o),
                                                           p(lp_o), None, p(v_o), pol.infer_pb_ptr(), _lib.stream_ptr()), reps)
+    # the loop's env step: policy + sampling + env step of every 32-env tile in ONE launch
+    t_roll = _time_launches(lambda: lib.ppo_rollout_step(env._handle, C.byref(env._bufs), p(pol.P), p(pol.PF), p(xs), p(eps),
+                                                         p(var), 0, 0.0, 0.0, p(a_o), p(lp_o), p(v_o), _lib.stream_ptr()), reps)
+    env.exit()
     t_gw = _time_launches(lambda: lib.mlp_grad_w(p(x), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(d["dz1"]), p(d["dz2"]),
                                                  p(d["dz3"]), p(d["dz4"]), rows, p(pol.workspace), p(pol.G), None, None, None,
                                                  _lib.stream_ptr()), reps)
@@ -135,13 +138,17 @@ def kernel_rooflines(num_envs, T, reps):
                 "launches_per_iteration": per_iter, "iteration_share_ms": round(dur * per_iter * 1e3, 3)}
 
     ks = [
-        hbm("fly_kernel<63> (fly_step)", t_step, FUSED_STEP_BYTES_PER_ENV * num_envs, T),
+        # the rollout's ONE launch per env step = policy forward + sampling + fused env step; priced as MFMA work
+        # (its forward half) -- the env half is VALU-issue-bound, see the stand-alone fly_kernel entry below
+        mfma("rollout_step_kernel (policy + sample + env step, %d envs)" % num_envs, t_roll, MLP_FWD_FLOP * num_envs, T),
+        # north_star's physics kernel on its own (not launched by the default loop any more: share 0)
+        hbm("fly_kernel<63> (fly_step)", t_step, FUSED_STEP_BYTES_PER_ENV * num_envs, 0),
         # the update's forward + loss + dX chain of one 40 960-row minibatch is ONE launch
         # bf16x3 mode: six bf16 MFMA terms per product, so the algorithmic-FLOP roofline is the dense bf16 peak / 6
         mfma("mlp_fwd_bwd_kernel", t_fb, (MLP_FWD_FLOP + MLP_BWD_DX_FLOP) * rows, 75,
              PEAK_F32_MFMA_TFLOPS if pol.gemm == "f32" else round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)),
-        # rollout policy + sampling (+ v(obs_t)) of num_envs rows, and once per iteration v(last next_obs)
-        mfma("mlp_forward_kernel (policy + sample, %d rows)" % num_envs, t_pol, MLP_FWD_FLOP * num_envs, T + 1),
+        # the forward body alone at num_envs rows: once per iteration for v(last next_obs)
+        mfma("mlp_forward_kernel (policy + sample, %d rows)" % num_envs, t_pol, MLP_FWD_FLOP * num_envs, 1),
         mfma("mlp_grad_w_kernel (+reduce)", t_gw, MLP_GRAD_W_FLOP * rows, 75),
         hbm("mlp_adam_kernel", t_adam, 74272 * 4 * 7, 75),
     ]
@@ -157,6 +164,7 @@ def kernel_rooflines(num_envs, T, reps):
         traffic = {}
     grids = {"fly_kernel<63> (fly_step)": ("fly_kernel<63>", ((num_envs + 31) // 32) * 256),
              "mlp_fwd_bwd_kernel": ("mlp_fwd_bwd_kernel", 2 * ((rows + 31) // 32) * 256),
+             "rollout_step_kernel (policy + sample + env step, %d envs)" % num_envs: ("rollout_step_kernel", ((num_envs + 31) // 32) * 256),
              "mlp_forward_kernel (policy + sample, %d rows)" % num_envs: ("mlp_forward_kernel", ((num_envs + 31) // 32) * 256),
              "mlp_grad_w_kernel (+reduce)": ("mlp_grad_w_kernel", 256 * 1024)}
     for k in ks:

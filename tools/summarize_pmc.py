@@ -22,7 +22,7 @@ WIDE_READS = ("mlp_forward_kernel", "mlp_backward_dx_kernel", "mlp_fwd_bwd_kerne
 
 
 def short(name):
-    m = re.search(r"(fly_kernel<\d+>|mlp_\w+_kernel|ppo_\w+_kernel|dqn_\w+_kernel)", name)
+    m = re.search(r"(fly_kernel<\d+>|mlp_\w+_kernel|ppo_\w+_kernel|dqn_\w+_kernel|rollout_step_kernel)", name)
     return m.group(1) if m else None
 
 
