@@ -272,15 +272,17 @@ def test_bf16x3_forward_is_fp32_accurate(n):
         assert a <= 2e-5 and a <= 2.0 * b + 1e-7, err
 
 
-def test_one_launch_rollout_step_equals_two_launches():
+@pytest.mark.parametrize("n", [4096, 1000])
+def test_one_launch_rollout_step_equals_two_launches(n):
     """ppo_rollout_step (policy + sampling + env step of each 32-env tile in one launch) leaves bit for
-    bit what mlp_forward_sample followed by fly_step leave, over a whole rollout plus the next one."""
+    bit what mlp_forward_sample followed by fly_step leave, over a whole rollout plus the next one
+    (1000 envs: the trainer's default, a ragged last tile)."""
     from fly_bproject_amd.ppo import PPO
     res = {}
     for fuse in (True, False):
         torch.manual_seed(0)
         with contextlib.redirect_stdout(io.StringIO()):
-            agent = PPO(make_args(4096, testing=True))
+            agent = PPO(make_args(n, testing=True))
             agent.run()
             assert agent.fuse_rollout_step
             agent.fuse_rollout_step = fuse
