@@ -194,7 +194,7 @@ def cpu_baseline(num_envs):
     net = PO.OracleNet()
     var = torch.full((18,), 0.2)
     rng = np.random.default_rng(0)
-    S, M = 24, 6
+    S, M = 480, 120         # ~2 s of env steps + ~12 s of minibatch steps on the box's 16 host cores
     obs = torch.zeros(num_envs, 73)
     O.env_step(cfg, s, np.zeros((num_envs, 18), np.float32))      # warm caches / threads
     t0 = time.perf_counter()
