@@ -188,7 +188,7 @@ int ppo_adv_apply(float* adv, int64_t n, const float* totals, float count, float
 int ppo_step_bookkeeping(const float* reward, int64_t n, float* score_acc, float score_scale,
                          float* action_var, int32_t nvar, float var_decay, float var_min, void* stream);
 
-/* The same bookkeeping for `rows` consecutive env steps in two small launches, bit for bit what
+/* ppo.py:233 and :236-237 for `rows` consecutive env steps in two small launches, bit for bit what
  * `rows` calls of ppo_step_bookkeeping on the rows of reward f32 [rows][n] leave (score terms are
  * added in row order, the variance is decayed `rows` times).  `terms` is a device scratch of
  * >= rows floats.  The rollout calls it when the score is printed and before an update instead of
@@ -278,7 +278,9 @@ int mlp_backward_dx(const float* params_t_frag, const float* out_saved, const fl
                     int64_t n, float inv_batch, float clip, float* dz4, float* dz3, float* dz2,
                     float* dz1, float* loss_part, const uint16_t* params_t_b3, void* stream);
 
-/* mlp_forward (activations saved) and mlp_backward_dx of the same n rows in ONE launch: both are
+/* The forward and the loss + dX chain of one PPO minibatch (ppo.py:184-197: net.pi / net.v on the
+ * minibatch, ratio, clipped surrogate, smooth_l1, backward down to the first layer's pre-activations)
+ * -- i.e. mlp_forward (activations saved) and mlp_backward_dx of the same n rows -- in ONE launch: both are
  * row-local, so the backward workgroup of a 32-row tile starts as soon as that tile's forward has
  * published its flag, and fills the slots the forward launch's ragged tail would leave idle.
  * Results are bit-identical to the two separate calls.  `flags` int32 [ceil(n/32)] device scratch
