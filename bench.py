@@ -35,7 +35,34 @@ def parse():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_alt_gemm", action="store_true", help="skip the secondary bf16x3 measurement")
     ap.add_argument("--kernel_reps", type=int, default=200)
+    ap.add_argument("--dry_run", action="store_true",
+                    help="rank plumbing only (spawn, rendezvous, barrier, max-over-ranks timing, the JSON line) with no "
+                         "GPU work: what the CPU/gloo test of --gpus N exercises")
     return ap.parse_args()
+
+
+def spawn_ranks(a):
+    """`bench.py --gpus N` without an external launcher: start N rank processes (one per GPU) BEFORE this
+    process touches the GPU, hand each the torch.distributed.run environment (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_*), and wait.  Rank 0's stdout carries the one JSON line.  Children are plain
+    child processes (never an exec of a GPU-initialised parent)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def make_args(n, **kw):
@@ -233,12 +260,47 @@ def cpu_baseline(num_envs):
             "rollout_env_steps_per_s": round(num_envs / t_step, 1)}
 
 
+def dry_run(a):
+    """The rank plumbing of main() with the GPU work replaced by a sleep: rendezvous (gloo), fence,
+    K timed "steps", max over ranks, one JSON line on rank 0."""
+    from fly_bproject_amd.dist import init_from_env
+    os.environ.setdefault("FLY_DIST_BACKEND", "gloo")
+    rank, _, world = init_from_env("cpu")
+    if world != a.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        time.sleep(0.01 * (1 + rank))                # ranks differ: the line must carry the MAX
+    if world > 1:
+        dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU work)", "value": 0.0, "unit": "env-steps/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(float(tt[0]) / a.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic", "dry_run": True,
+                          "config": {"workload": "dry_run", "parallelism": "dp%d" % world}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))                    # before anything touches the GPU
+    if a.dry_run:
+        return dry_run(a)
     from fly_bproject_amd.dist import broadcast_policy, init_from_env
     from fly_bproject_amd.ppo import PPO
 
     rank, local_rank, world = init_from_env("cuda")
+    if world != a.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (the launcher and the flag must agree)" % (a.gpus, world))
     if os.environ.get("FLY_SINGLE_GPU"):         # rehearsal of the N>1 path on a one-GPU box (gloo transport)
         local_rank = 0
     torch.cuda.set_device(local_rank)

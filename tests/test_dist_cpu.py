@@ -97,3 +97,30 @@ def test_flat_grad_aliasing_guard():
     torch.optim.SGD(net.parameters(), lr=0.1).zero_grad(set_to_none=True)
     with pytest.raises(RuntimeError):
         flat.allreduce_mean()
+
+
+def _run_bench(extra, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + extra, env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, [json.loads(ln) for ln in lines]
+
+
+def test_bench_gpus_flag_spawns_that_many_ranks():
+    """`bench.py --gpus 2` with no external launcher must start two rank processes itself (before any
+    GPU call), rendezvous them, take the max over ranks and print ONE line with n_gpus == 2."""
+    r, lines = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "0", "--dry_run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["config"]["parallelism"] == "dp2"
+    assert lines[0]["ms_per_step"] >= 19.0          # rank 1 sleeps 20 ms per step: the MAX over ranks is reported
+
+
+def test_bench_refuses_a_launcher_that_disagrees_with_gpus():
+    r, lines = _run_bench(["--gpus", "2", "--dry_run"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and not lines

@@ -54,3 +54,24 @@ def test_two_ranks_one_gpu(tmp_path, dp_mode):
     assert a["finite"] and b["finite"]
     assert torch.equal(a["P"], b["P"]) and torch.equal(a["PF"], b["PF"])     # replicas in lock step
     assert not torch.equal(a["acts"], b["acts"])                              # but different rollouts
+
+
+def test_bench_gpus_2_on_one_gpu():
+    """bench.py's own rank spawning end to end on the one-GPU box: `--gpus 2` starts two ranks (both
+    on cuda:0, gloo transport), each runs a full PPO iteration with the per-step gradient all-reduce,
+    and rank 0 prints one line with n_gpus == 2 and twice the env-steps of one rank."""
+    import json
+    import subprocess
+    env = dict(os.environ, FLY_SINGLE_GPU="1", FLY_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--num_envs", "2048", "--no_cpu_baseline", "--no_alt_gemm", "--kernel_reps", "5"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["params_finite"]
+    T = line["config"]["rollout_size"]
+    assert abs(line["value"] * line["ms_per_step"] * 1e-3 - 2 * 2048 * T) < 1e-3 * 2 * 2048 * T

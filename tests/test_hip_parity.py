@@ -218,30 +218,58 @@ def test_fused_step_vs_oracle_resynced(variant):
 
 def test_fused_step_vs_reference_golden(golden):
     """The reference's own Fly.step orchestration (g3, recorded with FlyDyn plugged in as
-    simulate()): restart from the recorded state each step, compare the next recorded step."""
+    simulate()): restart from the recorded state each step, compare EVERY recorded field of the next
+    step: progress and reset masks bit for bit, root / joints / potentials / all 73 observation
+    columns (angles on the circle) / reward within the stated fp32 tolerances."""
     g = golden("g3_step")
+    checked_reward = checked_reset = 0
     for variant in ("bigGrav", "lowGrav"):
         acts = g[variant + "_actions"]
         steps, n, _ = acts.shape
         cfg = O.default_config(n, variant)
         env = make_env(n, variant)
         s = O.EnvState(n)
+        R = lambda k: g[variant + "_" + k][t]   # noqa: E731
         for t in range(steps):
             push_state(env, s)
             env.step(cuda(acts[t]))
             got = pull_state(env)
             O.env_step(cfg, s, acts[t])                     # == golden (asserted in the CPU suite)
+            ref_progress = R("progress").copy()
             if t == 20:
-                s.progress[3] = 1497
-            assert np.array_equal(got.progress if t != 20 else s.progress * 0 + got.progress, got.progress)
-            np.testing.assert_allclose(got.root[:, :7], g[variant + "_root"][t][:, :7], rtol=2e-4, atol=2e-4)
-            ref_reset = g[variant + "_reset"][t]
-            z = g[variant + "_root"][t][:, 2]
-            safe = (np.abs(z - 1.1) > 1e-3)
+                ref_progress[3] = s.progress[3]             # the fixture holds the generator's override for env 3 here ...
+                s.progress[3] = 1497                        # ... applied AFTER step 20 (so step 21 must count 1498, and reset at 1499)
+            assert np.array_equal(got.progress, ref_progress), (variant, t)
+            ref_root = R("root")
+            np.testing.assert_allclose(got.root[:, :7], ref_root[:, :7], rtol=2e-4, atol=2e-4)
+            np.testing.assert_allclose(got.root[:, 7:], ref_root[:, 7:], rtol=5e-3, atol=5e-3)
+            np.testing.assert_allclose(got.dof_pos, R("dof_pos"), rtol=2e-4, atol=2e-4)
+            np.testing.assert_allclose(got.dof_vel, R("dof_vel"), rtol=5e-3, atol=5e-3)
+            # potentials = -|target - pos| / dt: position tolerance x 60, on a value of ~ -6e4
+            np.testing.assert_allclose(got.pot, R("pot"), rtol=1e-6, atol=2e-2)
+            np.testing.assert_allclose(got.prev_pot, R("prev_pot"), rtol=1e-6, atol=2e-2)
+            ref_obs, ref_reset = R("obs"), R("reset")
+            z, ori = ref_root[:, 2], ref_root[:, 5] ** 2 + ref_root[:, 6] ** 2
+            abd = s.contact[:, :5].sum(axis=(1, 2))
+            safe = (np.abs(z - 1.1) > 1e-3) & (np.abs(z - 6) > 1e-3) & (np.abs(ori - 0.5) > 1e-3) & \
+                ((abd == 0) | (np.abs(abd) > 1e-3))
             assert np.array_equal(got.reset[safe], ref_reset[safe]), (variant, t)
-            np.testing.assert_allclose(got.obs[:, 12:30], g[variant + "_obs"][t][:, 12:30], rtol=2e-4, atol=2e-4)
-            assert np.array_equal(got.obs[:, 48:66], g[variant + "_obs"][t][:, 48:66])
+            checked_reset += int(ref_reset[safe].sum())
+            lin = [0, 1, 2, 3, 4, 5, 6, 10, 11]
+            np.testing.assert_allclose(got.obs[:, lin], ref_obs[:, lin], rtol=5e-3, atol=5e-3)
+            for col in (7, 8, 9, 66):                       # angles live on a circle: 0 == 2*pi
+                dang = np.abs((got.obs[:, col] - ref_obs[:, col] + np.pi) % (2 * np.pi) - np.pi)
+                assert dang.max() < 5e-3, (variant, t, col, dang.max())
+            np.testing.assert_allclose(got.obs[:, 12:30], ref_obs[:, 12:30], rtol=2e-4, atol=2e-4)
+            np.testing.assert_allclose(got.obs[:, 30:48], ref_obs[:, 30:48], rtol=5e-3, atol=5e-3)      # dof_vel * 0.2
+            assert np.array_equal(got.obs[:, 48:66], ref_obs[:, 48:66])
+            touch_same = np.all(got.obs[:, 67:] == ref_obs[:, 67:], axis=1)
+            assert touch_same.mean() > 0.8, (variant, t)     # a foot within rounding of the ground may flip its flag
+            stable = safe & touch_same & (np.abs(z - 1.4) > 1e-3) & (np.abs(z - 2.1) > 1e-3) & (np.abs(ori - 0.98) > 1e-3)
+            np.testing.assert_allclose(got.reward[stable], R("reward")[stable], rtol=1e-5, atol=1e-5)
+            checked_reward += int(stable.sum())
         env.exit()
+    assert checked_reward > 1000 and checked_reset > 0
 
 
 def test_fused_equals_unfused_bit_exact():
