@@ -177,7 +177,17 @@ class PPO:
 
     @action_var.setter
     def action_var(self, value):
-        self._action_var = value
+        """The reference rebinds this attribute (ppo.py:237); here the rollout launches hold a POINTER to
+        the variance tensor, so an assignment first applies the decays still pending on the old value and
+        then writes the new one in place -- every later launch (sampling, log-prob, loss) sees it."""
+        if getattr(self, "_action_var", None) is None:
+            self._action_var = value
+            return
+        if getattr(self, "_book_terms", None) is not None:
+            self._flush_bookkeeping()
+        with torch.no_grad():
+            v = torch.as_tensor(value, dtype=torch.float32, device=self._action_var.device)
+            self._action_var.copy_(v.expand_as(self._action_var))
 
     def _flush_bookkeeping(self):
         """Apply the score terms and variance decays of rollout rows [_book_from, _rows_done)."""

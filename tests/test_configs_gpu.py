@@ -1,0 +1,171 @@
+"""GPU (-m gpu): every configuration BASELINE.json lists, at its full size, through the product path.
+
+  configs[1]  4096 envs, fp32                         -> tests/test_ppo_gpu.py (two iterations)
+  configs[2]  16384 envs, bf16(x3) MLP on the bf16 MFMA pipe + hipGraph-captured rollout step   (here)
+  configs[3]  8 x 8192 envs, gradient all-reduce      -> 8192-env shard here; ranks in tests/test_dist_gpu.py
+  configs[4]  DQN, 32768 envs, HBM replay ring, eps-greedy + Huber-TD kernels                   (here)
+  log.txt     the reference's one recorded run: 300 envs -> mini_chunk 136, rollout 2176, 75 steps (here)
+"""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from tests.hip_helpers import make_args
+
+pytestmark = pytest.mark.gpu
+
+
+def _quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def _iterations(agent, k):
+    with _quiet():
+        for _ in range(k * agent.rollout_size):
+            agent.run()
+    torch.cuda.synchronize()
+
+
+def _snapshot(agent):
+    return dict(obs=agent._obs_ring.clone(), acts=agent.all_acts.clone(), rew=agent.all_reward.clone(),
+                logp=agent.all_log_prob.clone(), adv=agent.all_advantage.clone(), P=agent.policy.P.clone(),
+                m=agent.policy.exp_avg.clone(), progress=agent.env.progress_buf.clone(), root=agent.env.root_tensor.clone(),
+                var=agent.action_var.clone())
+
+
+def test_config2_16384_envs_bf16x3_with_captured_rollout():
+    """configs[2]: 16384 envs (T = 32), the MLP GEMMs on the bf16 matrix pipe (three-term splits), the
+    rollout step replayed from captured hipGraphs.  Two full PPO iterations each:
+      * graph + bf16x3 == eager + bf16x3 bit for bit (rollout tensors, advantages, parameters, Adam
+        moments, env state): capturing changes no value;
+      * bf16x3 vs the fp32-MFMA default after the first update: parameters within the suite's 2e-4
+        (the rollout before the first update is bit-identical: same weights, same eps)."""
+    from fly_bproject_amd.ppo import PPO
+    runs = {}
+    for tag, graph, gemm in (("eager_f32", False, "f32"), ("eager_b3", False, "bf16x3"), ("graph_b3", True, "bf16x3")):
+        torch.manual_seed(0)
+        with _quiet():
+            agent = PPO(make_args(16384, graph=graph))
+        agent.policy.gemm = gemm
+        assert agent.mini_chunk_size == 2 and agent.rollout_size == 32              # ppo.py:120-122
+        _iterations(agent, 1)
+        assert agent.optim_step == 75
+        first = _snapshot(agent)
+        _iterations(agent, 1)
+        assert agent.optim_step == 150
+        if graph:
+            assert len(agent._graphs) == agent.rollout_size                          # iteration 2 ran from the graphs
+        runs[tag] = (first, _snapshot(agent))
+        for k, v in runs[tag][1].items():
+            assert torch.isfinite(v.float()).all(), (tag, k)
+        agent.exit()
+    for it in (0, 1):
+        for k in runs["eager_b3"][it]:
+            assert torch.equal(runs["eager_b3"][it][k], runs["graph_b3"][it][k]), (it, k)
+    a, b = runs["eager_f32"][0], runs["eager_b3"][0]
+    for k in ("obs", "acts", "rew", "logp", "adv"):
+        assert torch.equal(a[k], b[k]), k                                             # same rollout before the first update
+    np.testing.assert_allclose(b["P"].cpu().numpy(), a["P"].cpu().numpy(), rtol=2e-4, atol=2e-4)
+    assert not torch.equal(a["P"], b["P"])                                            # but a different arithmetic did run
+
+
+def test_config3_shard_8192_envs_one_iteration():
+    """configs[3]'s per-GPU shard: 8192 envs, T = 80, 75 optimizer steps of 40 960 samples."""
+    from fly_bproject_amd.ppo import PPO
+    torch.manual_seed(0)
+    with _quiet():
+        agent = PPO(make_args(8192))
+    assert agent.mini_chunk_size == 5 and agent.rollout_size == 80
+    _iterations(agent, 1)
+    assert agent.optim_step == 75
+    s = _snapshot(agent)
+    for k, v in s.items():
+        assert torch.isfinite(v.float()).all(), k
+    assert int(agent.policy.tile_wait_error.item()) == 0
+    agent.exit()
+
+
+def test_log_txt_shape_300_envs():
+    """The reference's only recorded run (log.txt:24-25, :48-49): 300 envs -> mini_chunk_size 136,
+    rollout_size 2176, minibatches of 40 800 rows, 'Training' then Opt Step 0075, the variance printed
+    at step 2200 = start - 2200e-5 (log.txt:49: 0.1000 -> 0.0780)."""
+    from fly_bproject_amd.ppo import PPO
+    torch.manual_seed(0)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        agent = PPO(make_args(300))
+        agent.action_var = torch.full((18,), 0.1, device="cuda:0")                  # the run in log.txt started at 0.1
+        for _ in range(2201):
+            agent.run()
+    torch.cuda.synchronize()
+    out = buf.getvalue().splitlines()
+    assert "mini_chunk_size:  136" in out and "rollout_size:  2176" in out          # log.txt:24-25
+    assert agent.mini_chunk_size * 300 == 40800
+    assert agent.optim_step == 75
+    i_train = out.index("Training")
+    assert out[i_train - 1].startswith("Steps: 2100 | Opt Step: 0000")             # log.txt:47-48
+    assert out[i_train + 1].startswith("Steps: 2200 | Opt Step: 0075") and out[i_train + 1].endswith("Action Var 0.0780")
+    assert torch.isfinite(agent.policy.P).all() and torch.isfinite(agent._obs_ring).all()
+    agent.exit()
+
+
+def test_action_var_assignment_reaches_the_rollout_kernels():
+    """Drop-in code assigns `agent.action_var = ...` (the reference does, ppo.py:237).  The rollout
+    launches hold a pointer to the variance tensor: the assignment must be seen by the very next
+    sampling / log-prob launch, with pending lazy decays applied to the OLD value first."""
+    from fly_bproject_amd.ppo import PPO, diag_gauss_logprob
+    torch.manual_seed(0)
+    with _quiet():
+        agent = PPO(make_args(2048, testing=False))
+        for _ in range(3):
+            agent.run()
+        assert float(agent.action_var[0]) == pytest.approx(0.2 - 3e-5, rel=1e-6)
+        agent.action_var = torch.full((18,), 0.05, device="cuda:0")
+        t = agent.mini_batch_number
+        agent.run()
+    torch.cuda.synchronize()
+    assert float(agent.action_var[0]) == pytest.approx(0.05 - 1e-5, rel=1e-5)       # one more decay after the step
+    # the step at row t sampled and scored with variance 0.05: recompute its log-prob from the stored pieces
+    with torch.no_grad():
+        mu = agent.net.pi(agent._obs_ring[t])
+    var = torch.full((18,), 0.05, device="cuda:0")
+    unclipped = mu + var.sqrt() * agent._eps_all[t]
+    ref = diag_gauss_logprob(mu, unclipped, var)
+    np.testing.assert_allclose(agent.all_log_prob[t].cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-4)
+    assert torch.equal(agent.all_acts[t], unclipped.clamp(-1, 1)) or \
+        torch.allclose(agent.all_acts[t], unclipped.clamp(-1, 1), atol=1e-6)
+    agent.exit()
+
+
+def test_config4_dqn_32768_envs_hbm_replay():
+    """configs[4]: 32768 envs, replay ring in HBM with a STATED capacity (64 steps = 1.26 GB), per-env
+    eps-greedy and Huber-TD on the HIP kernels, 24 env steps with an update each (8 sampled steps =
+    262 144 rows per update): finite loss and parameters, the ring wraps nothing yet, and `act` on the
+    live Q table is bit-equal to the oracle's first-argmax / eps mix."""
+    from oracle import oracle as O
+    from fly_bproject_amd.dqn import DQN
+    torch.manual_seed(0)
+    n = 32768
+    with _quiet():
+        agent = DQN(make_args(n, dqn_mini_batch_size=8, replay_steps=64))
+    assert agent.replay.capacity == 64
+    assert agent.replay.bytes == 64 * n * (2 * 73 + 3) * 4                           # 1.25 GB, SURVEY §8(d)
+    with _quiet():
+        for _ in range(24):
+            agent.run()
+    torch.cuda.synchronize()
+    assert agent.replay.size() == 24 and agent.last_loss is not None
+    assert torch.isfinite(agent.last_loss)
+    for p in agent.q_parameters():
+        assert torch.isfinite(p).all()
+    obs = agent.env.obs_buf.clone()
+    for eps in (0.0, 0.3):
+        a = agent.act(obs, eps)
+        torch.cuda.synchronize()
+        q = agent.q_values(obs).cpu().numpy()
+        ref = O.dqn_eps_greedy(q, agent._coin.cpu().numpy(), agent._rand.cpu().numpy(), eps)
+        assert np.array_equal(a.cpu().numpy(), ref), eps
+    agent.exit()
