@@ -127,13 +127,15 @@ def kernel_rooflines(num_envs, T, reps):
     err = torch.zeros(1, dtype=torch.int32, device="cuda:0")
     epoch = [0]
 
-    def fwd_bwd():
+    def fwd_bwd(coherent=1):
         epoch[0] += 1
         lib.mlp_forward_backward(p(pol.P), p(pol.PF), p(pol.PT), p(x), rows, p(s["out"]), p(s["h1"]), p(s["h2"]), p(s["h3"]),
                                  p(act), p(olp), p(adv), p(tgt), p(var), 1.0 / rows, 0.2, p(d["dz4"]), p(d["dz3"]),
                                  p(d["dz2"]), p(d["dz1"]), p(pol.loss_part), p(flags), epoch[0], p(err), pol.pb_ptr(), pol.ptb_ptr(),
-                                 _lib.stream_ptr())
-    t_fb = _time_launches(fwd_bwd, reps)
+                                 coherent, _lib.stream_ptr())
+    t_fb = _time_launches(lambda: fwd_bwd(1 if pol.handoff == "sc1" else 0), reps)
+    # A/B of the tile hand-off inside the launch: sc1 write-through + L1-bypassing loads vs plain accesses on one XCD
+    t_fb_alt = _time_launches(lambda: fwd_bwd(0 if pol.handoff == "sc1" else 1), reps)
     assert int(err.item()) == 0, "mlp_forward_backward reported a lost tile flag"
     xs = torch.randn(num_envs, 73, device="cuda:0")
     eps = torch.randn(num_envs, 18, device="cuda:0")
@@ -147,7 +149,7 @@ def kernel_rooflines(num_envs, T, reps):
     env.exit()
     t_gw = _time_launches(lambda: lib.mlp_grad_w(p(x), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(d["dz1"]), p(d["dz2"]),
                                                  p(d["dz3"]), p(d["dz4"]), rows, p(pol.workspace), p(pol.G), None, None, None,
-                                                 _lib.stream_ptr()), reps)
+                                                 None, _lib.stream_ptr()), reps)
     t_adam = _time_launches(lambda: pol.adam_step(), reps)
 
     def hbm(name, dur, bytes_per_launch, per_iter):
@@ -200,6 +202,10 @@ def kernel_rooflines(num_envs, T, reps):
             t = traffic.get("%s@%d" % key)
             if t:
                 k["traffic"] = t["hbm_bytes_per_launch"]
+    for k in ks:
+        if k["kernel"] == "mlp_fwd_bwd_kernel":
+            k["handoff"] = pol.handoff
+            k["other_handoff_avg_launch_us"] = {("xcd" if pol.handoff == "sc1" else "sc1"): round(t_fb_alt * 1e6, 3)}
     ks.sort(key=lambda k: -k["iteration_share_ms"])
     return ks
 

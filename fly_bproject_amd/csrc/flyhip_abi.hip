@@ -30,7 +30,7 @@ extern "C" int64_t flyhip_mlp_grad_workspace_floats(void);
 extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, const float* h2, const float* h3,
                                                const float* dz1, const float* dz2, const float* dz3, const float* dz4,
                                                int64_t n, float* workspace, float* grad_out, const float* norm_mask,
-                                               float* norm_ws, int* norm_step, void* stream);
+                                               float* norm_ws, int* norm_step, const int* err, void* stream);
 extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PF, float* PT, const int* idx_f, const int* idx_t,
                                              const float* G, const float* mask, float* m,
                                              float* v, int* step, float lr, float beta1, float beta2, float eps,
@@ -60,7 +60,7 @@ extern "C" hipError_t flyhip_launch_mlp_fwd_bwd(const float* P, const float* PF,
                                                 const float* target, const float* var, float inv_batch, float clip,
                                                 float* dz4, float* dz3, float* dz2, float* dz1, float* loss_part,
                                                 int* flags, int epoch, int* err, const uint16_t* PB, const uint16_t* PTB,
-                                                void* stream);
+                                                int coherent, void* stream);
 extern "C" hipError_t flyhip_launch_rollout_bookkeeping(const float* reward, int64_t rows, int64_t n, float* terms,
                                                         float* score_acc, float score_scale, float* action_var, int nvar,
                                                         float var_decay, float var_min, void* stream);
@@ -132,7 +132,7 @@ int launch(FlyHandle h, int phases, const float* actions, const FlyBuffers* b, v
 extern "C" {
 
 const char* fly_last_error(void) { return g_err; }
-int fly_abi_version(void) { return 5; }
+int fly_abi_version(void) { return 6; }
 
 int fly_create(const FlyConfig* cfg, FlyHandle* out)
 {
@@ -318,7 +318,7 @@ int mlp_forward_backward(const float* params, const float* params_frag, const fl
                          const float* target, const float* var, float inv_batch, float clip,
                          float* dz4, float* dz3, float* dz2, float* dz1, float* loss_part,
                          int32_t* flags, int32_t epoch, int32_t* err, const uint16_t* params_b3,
-                         const uint16_t* params_t_b3, void* stream)
+                         const uint16_t* params_t_b3, int32_t coherent, void* stream)
 {
     if ((params_b3 == nullptr) != (params_t_b3 == nullptr))
         return fail(FLY_E_ARG, "mlp_forward_backward: params_b3 and params_t_b3 go together");
@@ -329,7 +329,7 @@ int mlp_forward_backward(const float* params, const float* params_frag, const fl
     if (epoch <= 0 || epoch >= (1 << 27)) return fail(FLY_E_ARG, "mlp_forward_backward: epoch must be in [1, 2^27)");
     hipError_t e = flyhip_launch_mlp_fwd_bwd(params, params_frag, params_t_frag, x, n, out_save, h1_save, h2_save, h3_save,
                                              action, old_logp, adv, target, var, inv_batch, clip, dz4, dz3, dz2, dz1,
-                                             loss_part, flags, epoch, err, params_b3, params_t_b3, stream);
+                                             loss_part, flags, epoch, err, params_b3, params_t_b3, coherent, stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_forward_backward launch");
     return FLY_OK;
 }
@@ -337,7 +337,7 @@ int mlp_forward_backward(const float* params, const float* params_frag, const fl
 int mlp_grad_w(const float* x, const float* h1_saved, const float* h2_saved, const float* h3_saved,
                const float* dz1, const float* dz2, const float* dz3, const float* dz4, int64_t n,
                float* workspace, float* grad, const float* norm_mask, float* norm_ws, int32_t* norm_step,
-               void* stream)
+               const int32_t* err, void* stream)
 {
     if ((norm_ws != nullptr) != (norm_mask != nullptr) || (norm_ws != nullptr) != (norm_step != nullptr))
         return fail(FLY_E_ARG, "mlp_grad_w: norm_mask, norm_ws and norm_step go together");
@@ -345,7 +345,7 @@ int mlp_grad_w(const float* x, const float* h1_saved, const float* h2_saved, con
         return fail(FLY_E_ARG, "mlp_grad_w: null pointer");
     if (n <= 0) return fail(FLY_E_ARG, "mlp_grad_w: n must be > 0");
     hipError_t e = flyhip_launch_mlp_grad_w(x, h1_saved, h2_saved, h3_saved, dz1, dz2, dz3, dz4, n, workspace, grad, norm_mask,
-                                            norm_ws, norm_step, stream);
+                                            norm_ws, norm_step, err, stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_grad_w launch");
     return FLY_OK;
 }

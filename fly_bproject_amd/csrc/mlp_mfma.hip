@@ -157,26 +157,31 @@ static void gw_read_env()
         for (int i = 0; i < 4; ++i) kGradWgs[i] = v[i];
 }
 
+static int g_fb_consumer_shift = 0;     // test hook: moves the consumer range off its producers' XCDs (forces err = 2 in xcd mode)
+extern "C" void flyhip_debug_set_fwd_bwd_consumer_shift(int shift) { g_fb_consumer_shift = shift; }
+
 extern "C" hipError_t flyhip_launch_mlp_fwd_bwd(const float* P, const float* PF, const float* PT, const float* x, int64_t n,
                                                 float* out_save, float* h1_save, float* h2_save, float* h3_save,
                                                 const float* action, const float* old_logp, const float* adv,
                                                 const float* target, const float* var, float inv_batch, float clip,
                                                 float* dz4, float* dz3, float* dz2, float* dz1, float* loss_part,
                                                 int* flags, int epoch, int* err, const uint16_t* PB, const uint16_t* PTB,
-                                                void* stream)
+                                                int coherent, void* stream)
 {
     const long tiles = (n + BM - 1) / BM;
-    const long pad_tiles = (tiles + 7) & ~7L;
-    if (PB && PTB)
-        hipLaunchKernelGGL((mlp_fwd_bwd_kernel<false, true>), dim3((unsigned)(pad_tiles + tiles)), dim3(THREADS), 0,
-                           (hipStream_t)stream, P, (const void*)PB, (const void*)PTB, x, (long)n, out_save, h1_save, h2_save,
-                           h3_save, action, old_logp, adv, target, var, inv_batch, clip, dz4, dz3, dz2, dz1, loss_part, flags,
-                           epoch, err, (unsigned long long*)nullptr);
-    else
-        hipLaunchKernelGGL((mlp_fwd_bwd_kernel<false, false>), dim3((unsigned)(pad_tiles + tiles)), dim3(THREADS), 0,
-                           (hipStream_t)stream, P, (const void*)PF, (const void*)PT, x, (long)n, out_save, h1_save, h2_save,
-                           h3_save, action, old_logp, adv, target, var, inv_batch, clip, dz4, dz3, dz2, dz1, loss_part, flags,
-                           epoch, err, (unsigned long long*)nullptr);
+    const int shift = g_fb_consumer_shift;
+    const long pad_tiles = ((tiles + 7) & ~7L) + shift;
+    const dim3 grid((unsigned)(pad_tiles + tiles));
+    const bool b3 = PB && PTB;
+    const void* pf = b3 ? (const void*)PB : (const void*)PF;
+    const void* pt = b3 ? (const void*)PTB : (const void*)PT;
+#define FB_LAUNCH(B3_, COH_)                                                                                                   \
+    hipLaunchKernelGGL((mlp_fwd_bwd_kernel<false, B3_, COH_>), grid, dim3(THREADS), 0, (hipStream_t)stream, P, pf, pt, x,      \
+                       (long)n, out_save, h1_save, h2_save, h3_save, action, old_logp, adv, target, var, inv_batch, clip, dz4, \
+                       dz3, dz2, dz1, loss_part, flags, epoch, err, (unsigned long long*)nullptr, shift)
+    if (b3) { if (coherent) FB_LAUNCH(true, true); else FB_LAUNCH(true, false); }
+    else { if (coherent) FB_LAUNCH(false, true); else FB_LAUNCH(false, false); }
+#undef FB_LAUNCH
     return hipGetLastError();
 }
 
@@ -190,9 +195,9 @@ extern "C" int flyhip_debug_mlp_fwd_bwd_stamped(const float* P, const float* PF,
 {
     const long tiles = (n + BM - 1) / BM;
     const long pad_tiles = (tiles + 7) & ~7L;
-    hipLaunchKernelGGL((mlp_fwd_bwd_kernel<true, false>), dim3((unsigned)(pad_tiles + tiles)), dim3(THREADS), 0, (hipStream_t)stream, P,
+    hipLaunchKernelGGL((mlp_fwd_bwd_kernel<true, false, true>), dim3((unsigned)(pad_tiles + tiles)), dim3(THREADS), 0, (hipStream_t)stream, P,
                        (const void*)PF, (const void*)PT, x, (long)n, out_save, h1_save, h2_save, h3_save, action, old_logp, adv, target, var, inv_batch,
-                       clip, dz4, dz3, dz2, dz1, loss_part, flags, epoch, err, stamps);
+                       clip, dz4, dz3, dz2, dz1, loss_part, flags, epoch, err, stamps, 0);
     return (int)hipGetLastError();
 }
 
@@ -216,7 +221,7 @@ extern "C" int64_t flyhip_mlp_grad_workspace_floats(void)
 extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, const float* h2, const float* h3,
                                                const float* dz1, const float* dz2, const float* dz3, const float* dz4,
                                                int64_t n, float* workspace, float* grad_out, const float* norm_mask,
-                                               float* norm_ws, int* norm_step, void* stream)
+                                               float* norm_ws, int* norm_step, const int* err, void* stream)
 {
     gw_read_env();
     GradWTable T;
@@ -247,7 +252,7 @@ extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3(RED_BLOCKS), dim3(64 * RED_WAVES), 0,
-                       (hipStream_t)stream, T, grad_out, norm_mask, norm_ws, norm_step);
+                       (hipStream_t)stream, T, grad_out, norm_mask, norm_ws, norm_step, err);
     return hipGetLastError();
 }
 

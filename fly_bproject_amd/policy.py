@@ -257,6 +257,7 @@ class PackedPolicy:
         self.exp_avg = torch.zeros(PACKED, device=dev)
         self.exp_avg_sq = torch.zeros(PACKED, device=dev)
         self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.steps_issued = 0              # adam_step calls so far; the device counter lags iff a step was refused (fail closed)
         self._norm_ws = torch.zeros(1280, device=dev)      # [0] = pre-clip gradient norm, rest partial sums
         self.grad_norm = self._norm_ws[:1]
         self.workspace = torch.empty(int(self._lib.mlp_grad_workspace_floats()), device=dev)
@@ -273,28 +274,34 @@ class PackedPolicy:
         self.tile_wait_error = torch.zeros(1, dtype=torch.int32, device=dev)
         self._epoch = 0
         self.fuse_fwd_bwd = os.environ.get("FLY_FUSE_FWD_BWD", "1") != "0"
+        # how a tile travels from its forward to its backward workgroup inside the one launch
+        # (csrc/mlp_backward.inc): "sc1" = write-through stores + L1-bypassing loads, no placement
+        # assumption (default); "xcd" = plain accesses, producer and consumer must share an XCD
+        self.handoff = os.environ.get("FLY_FWD_BWD_HANDOFF", "sc1")
+        assert self.handoff in ("sc1", "xcd")
         if self.fuse_fwd_bwd:
             self._probe_fused_launch()
 
     def _probe_fused_launch(self):
-        """mlp_forward_backward relies on a tile's forward and backward workgroups sharing an XCD (its
-        err word says if they do not).  One small launch over 64 tiles (8 per XCD) at start-up decides:
-        on a device that places workgroups differently the two-launch path is used instead --
-        same results, the kernel never guesses."""
+        """One small fused launch over 64 tiles (8 per XCD) at start-up: if a backward workgroup cannot
+        get its tile (no in-order dispatch: err 1; "xcd" hand-off on a device that places workgroups
+        differently: err 2) the two-launch path is used from the start -- same results."""
         n = min(self.max_rows, 64 * 32)
         z = lambda *shape: torch.zeros(*shape, device=self.device)   # noqa: E731
         self.minibatch_grad(z(n, IN), z(n, NACT), z(n), z(n), z(n), torch.full((NACT,), 0.2, device=self.device), 0.2)
         self.check_fused_launch()
 
     def check_fused_launch(self):
-        """Host sync.  Raises if a fused launch lost a tile flag (results of that call are invalid);
-        switches to the two-launch path if the device does not co-locate producer and consumer."""
+        """Host sync.  Returns the err word of the fused launches since the last check (0 = all fine) and
+        clears it; a nonzero word switches this policy to the two-launch path.  The optimizer kernels
+        have already refused every step whose gradient came from a failed launch (they fail closed on
+        the device), so the caller only has to redo those minibatches (PPO._update_hip)."""
         err = int(self.tile_wait_error.item())
-        if err == 2:
+        if err != 0:
             self.fuse_fwd_bwd = False
+            self.fused_launch_failures = getattr(self, "fused_launch_failures", 0) + 1
             self.tile_wait_error.zero_()
-        elif err != 0:
-            raise _lib.FlyHipError("mlp_forward_backward: a backward workgroup gave up waiting for its tile (err=%d)" % err)
+        return err
 
     def minibatch_grad(self, x, action, old_logp, adv, target, var, clip, global_rows=None, fuse_norm=False):
         """Forward + loss + backward of one minibatch; leaves the packed gradient in `self.G`.
@@ -318,7 +325,8 @@ class PackedPolicy:
                 p(self.P), p(self.PF), p(self.PT), p(x), C.c_int64(n), p(s["out"]), p(s["h1"]), p(s["h2"]), p(s["h3"]),
                 p(action), p(old_logp), p(adv), p(target), p(var), C.c_float(inv_b), C.c_float(clip),
                 p(d["dz4"]), p(d["dz3"]), p(d["dz2"]), p(d["dz1"]), p(self.loss_part), p(self._tile_flags),
-                C.c_int(self._epoch), p(self.tile_wait_error), self.pb_ptr(), self.ptb_ptr(), st), "mlp_forward_backward")
+                C.c_int(self._epoch), p(self.tile_wait_error), self.pb_ptr(), self.ptb_ptr(),
+                C.c_int(1 if self.handoff == "sc1" else 0), st), "mlp_forward_backward")
         else:
             _lib.check(self._lib.mlp_forward(p(self.P), p(self.PF), p(x), C.c_int64(n), None, None, p(s["out"]), p(s["h1"]),
                                              p(s["h2"]), p(s["h3"]), self.pb_ptr(), st), "mlp_forward")
@@ -328,7 +336,8 @@ class PackedPolicy:
                                                  p(self.loss_part), self.ptb_ptr(), st), "mlp_backward_dx")
         nm = (p(self.grad_mask), p(self._norm_ws), p(self.step)) if fuse_norm else (None, None, None)
         _lib.check(self._lib.mlp_grad_w(p(x), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(d["dz1"]), p(d["dz2"]),
-                                        p(d["dz3"]), p(d["dz4"]), C.c_int64(n), p(self.workspace), p(self.G), *nm, st),
+                                        p(d["dz3"]), p(d["dz4"]), C.c_int64(n), p(self.workspace), p(self.G), *nm,
+                                        p(self.tile_wait_error), st),
                    "mlp_grad_w")
 
     def loss_value(self, n):
@@ -339,6 +348,7 @@ class PackedPolicy:
     def adam_step(self, grad_scale=1.0, norm_ready=False):
         p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
         self.version += 1
+        self.steps_issued += 1
         _lib.check(self._lib.mlp_adam_step(p(self.P), p(self.PF), p(self.PT), p(self.idx_f), p(self.idx_t), p(self.G),
                                            p(self.grad_mask), p(self.exp_avg),
                                            p(self.exp_avg_sq), p(self.step), C.c_float(self.lr),

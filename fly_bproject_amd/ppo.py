@@ -291,9 +291,10 @@ class PPO:
         rows = mc * n
         pol = self.policy
         sync_grads = self.world_size > 1 and self.dp_mode == "grad_allreduce"
-        for _ in range(self.epoch):
-            k = 0
-            for j in range(mc, self.rollout_size, mc):
+        slices = [(j - mc, j) for _ in range(self.epoch) for j in range(mc, self.rollout_size, mc)]   # 5 x 15 (Q3)
+
+        def run(todo):
+            for k, j in todo:
                 pol.minibatch_grad(obs[k:j].view(rows, self.num_obs), action[k:j].view(rows, self.num_acts),
                                    old_log_prob[k:j].view(rows), advantage[k:j].view(rows),
                                    target[k:j].view(rows), self._action_var, self.clip,
@@ -301,12 +302,27 @@ class PPO:
                 if sync_grads:
                     dist.all_reduce(pol.G, op=dist.ReduceOp.SUM)    # 297 KB, latency-bound on xGMI
                 pol.adam_step(grad_scale=1.0 / self.world_size if sync_grads else 1.0, norm_ready=not sync_grads)
-                self.optim_step += 1
-                k = j
-        if pol.fuse_fwd_bwd:
-            pol.check_fused_launch()            # one host sync per update: a lost tile flag must never go unnoticed
-            if not pol.fuse_fwd_bwd:
-                raise _lib.FlyHipError("mlp_forward_backward: producer and consumer workgroups on different XCDs mid-run")
+
+        run(slices)
+        # ONE host sync per update.  A fused forward+backward launch whose backward could not get a tile
+        # leaves an invalid gradient; the optimizer kernels refuse such a step ON THE DEVICE (on every
+        # rank: the flag rides inside the all-reduced gradient), and every later step of this update too.
+        # So the device step counter says how many minibatches really happened: redo the rest through the
+        # two-launch path -- bit for bit what an undisturbed update leaves.
+        for attempt in range(3):
+            short = pol.steps_issued - int(pol.step.item())
+            if pol.fuse_fwd_bwd or short:
+                pol.check_fused_launch()
+            if short == 0:
+                break
+            if short < 0 or short > len(slices) or attempt == 2:
+                raise _lib.FlyHipError("update: device step counter is %d steps behind the %d issued" % (short, pol.steps_issued))
+            pol.fuse_fwd_bwd = False
+            pol.steps_issued -= short
+            print("mlp_forward_backward: %d of %d optimizer steps were refused on the device (a backward workgroup "
+                  "could not get its tile); redoing them with two launches" % (short, len(slices)))
+            run(slices[len(slices) - short:])
+        self.optim_step += len(slices)
         if self.world_size > 1 and not sync_grads:
             # dp_mode "param_average": ONE exchange per PPO update (BASELINE's north_star wording) --
             # ranks take their 75 optimizer steps locally, then parameters and Adam moments are

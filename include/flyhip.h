@@ -261,6 +261,10 @@ int ppo_rollout_step(FlyHandle h, const FlyBuffers* b, const float* params, cons
  *                     non-NULL (single rank: nothing sits between this call and the optimizer)
  *                     the reduction also leaves the clip-norm partial sums in norm_ws (>= 1280
  *                     floats) and advances *norm_step; pass norm_ready = 1 to mlp_adam_step then.
+ *                     `err` (optional) = the err word of mlp_forward_backward: while it is nonzero
+ *                     grad[76] (padding column 76 of W1 row 0: masked, never a parameter) is set
+ *                     to 1 instead of 0 and *norm_step is not advanced.  The flag rides inside the
+ *                     gradient so that a data-parallel all-reduce (sum) spreads it to every rank.
  *   mlp_adam_step   : grad *= grad_scale; clip_grad_norm_(max_norm); Adam with torch defaults on
  *                     `params`; every updated weight is also scattered into params_frag /
  *                     params_t_frag through idx_frag / idx_t_frag (int32 [MLP_PACKED_FLOATS_ABI],
@@ -269,7 +273,8 @@ int ppo_rollout_step(FlyHandle h, const FlyBuffers* b, const float* params, cons
  *                     512 and 1024 16-bit words later).  `mask` (packed layout, 0/1)
  *                     freezes padding and structural zeros.  `step` is a device int counter;
  *                     `norm_ws` is a device scratch of >= 1280 floats, norm_ws[0] returns the
- *                     pre-clip gradient norm.
+ *                     pre-clip gradient norm.  FAIL CLOSED: with grad[76] != 0 (see mlp_grad_w) the
+ *                     call changes nothing -- parameters, moments and *step keep their values.
  */
 int64_t mlp_grad_workspace_floats(void);
 int mlp_backward_dx(const float* params_t_frag, const float* out_saved, const float* h1_saved,
@@ -287,21 +292,28 @@ int mlp_backward_dx(const float* params_t_frag, const float* out_saved, const fl
  * (zero-initialised; re-zero it before `epoch` wraps), `epoch` in [1, 2^27) a value that differs
  * from every earlier call on these flags (a counter), `err` int32 [1] device word, normally 0:
  * 1 = a workgroup gave up waiting for its tile (the wait is bounded, a lost flag cannot hang the
- * device), 2 = a tile's forward and backward workgroups were not placed on the same XCD, which the
- * kernel relies on instead of L2 write-back/invalidate per workgroup.  Non-zero => results of
- * that call are invalid; use mlp_forward + mlp_backward_dx instead.  params_b3 / params_t_b3
- * (both or neither) select the bf16x3 GEMM arithmetic, see mlp_forward. */
+ * device), 2 = (coherent = 0 only) a tile's forward and backward workgroups were not on the same XCD.
+ * Assumptions, stated because HIP promises neither: LIVENESS needs workgroups to be dispatched in
+ * blockIdx order (a consumer's producer is resident or done before it polls; otherwise err = 1, never a
+ * hang).  VISIBILITY: coherent != 0 (the product default) hands the tile over with sc1 write-through
+ * stores, drained, an sc1 flag, and sc1 L1-bypassing loads on the consumer -- no placement assumption;
+ * coherent = 0 uses plain accesses and REQUIRES producer and consumer on one XCD (round-robin placement,
+ * checked through the XCC id, err = 2) and a consumer L1 that does not hold the tile's lines.
+ * Non-zero err => the dZ rows of that call are invalid: pass `err` to mlp_grad_w, which then marks the
+ * gradient (grad[76] = 1, a masked padding element) so that mlp_adam_step skips the step on every rank
+ * that receives it -- and redo the minibatch with mlp_forward + mlp_backward_dx.  params_b3 /
+ * params_t_b3 (both or neither) select the bf16x3 GEMM arithmetic, see mlp_forward. */
 int mlp_forward_backward(const float* params, const float* params_frag, const float* params_t_frag,
                          const float* x, int64_t n, float* out_save, float* h1_save, float* h2_save,
                          float* h3_save, const float* action, const float* old_logp, const float* adv,
                          const float* target, const float* var, float inv_batch, float clip,
                          float* dz4, float* dz3, float* dz2, float* dz1, float* loss_part,
                          int32_t* flags, int32_t epoch, int32_t* err, const uint16_t* params_b3,
-                         const uint16_t* params_t_b3, void* stream);
+                         const uint16_t* params_t_b3, int32_t coherent, void* stream);
 int mlp_grad_w(const float* x, const float* h1_saved, const float* h2_saved, const float* h3_saved,
                const float* dz1, const float* dz2, const float* dz3, const float* dz4, int64_t n,
                float* workspace, float* grad, const float* norm_mask, float* norm_ws, int32_t* norm_step,
-               void* stream);
+               const int32_t* err, void* stream);
 int mlp_adam_step(float* params, float* params_frag, float* params_t_frag, const int32_t* idx_frag,
                   const int32_t* idx_t_frag, const float* grad, const float* mask, float* exp_avg,
                   float* exp_avg_sq, int32_t* step, float lr, float beta1, float beta2, float eps,

@@ -237,3 +237,96 @@ def test_bf16x3_training_step_matches_fp32_path():
     for buf, src, dst in ((pol.PB, pol._src_fb, pol._dst_fb), (pol.PTB, pol._src_tb, pol._dst_tb)):
         for term, plane in enumerate(split_bf16x3(pol.P[src])):
             assert torch.equal(buf[dst + 512 * term], plane)
+
+
+@pytest.mark.parametrize("handoff", ["sc1", "xcd"])
+def test_fused_launch_handoff_modes_bit_equal_two_launches(handoff, monkeypatch):
+    """Both hand-off forms of mlp_forward_backward (sc1 write-through stores + L1-bypassing loads, no
+    placement assumption; plain accesses on one XCD) leave bit for bit what mlp_forward +
+    mlp_backward_dx leave, repeated over 6 launches on changing weights (a consumer that read a stale
+    line of the previous launch's activations would differ)."""
+    monkeypatch.setenv("FLY_FWD_BWD_HANDOFF", handoff)
+    n = 40960
+    net, ref, pol, batch = _setup(n, 11)
+    assert pol.handoff == handoff and pol.fuse_fwd_bwd
+    x, action, old_logp, adv, target, var = batch
+    for it in range(6):
+        pol.fuse_fwd_bwd = True
+        pol.minibatch_grad(x, action, old_logp, adv, target, var, 0.2)
+        fused = {k: v.clone() for k, v in list(pol.dz.items()) + list(pol.saves.items())}
+        g_fused = pol.G.clone()
+        assert pol.check_fused_launch() == 0
+        pol.fuse_fwd_bwd = False
+        for v in pol.dz.values():
+            v.fill_(float("nan"))
+        pol.minibatch_grad(x, action, old_logp, adv, target, var, 0.2)
+        for k, v in list(pol.dz.items()) + list(pol.saves.items()):
+            assert torch.equal(v, fused[k]), (it, k)
+        assert torch.equal(pol.G, g_fused), it
+        pol.adam_step()                                   # the next launch runs on different weights and activations
+        x = x + 0.01 * torch.randn_like(x)
+
+
+def test_failed_fused_launch_is_refused_on_the_device_and_redone():
+    """Force the failure the fused launch can have (consumer range shifted by one workgroup: in "xcd"
+    mode every tile's backward lands on another XCD than its forward -> err 2, no dZ written):
+      * the optimizer kernels refuse the step on the device: parameters, moments and the step counter do
+        not move, for that minibatch and for every later one while err is set;
+      * PPO.update notices the shortfall with its ONE host sync, switches to two launches, redoes exactly
+        the refused minibatches, and ends bit-identical to an undisturbed update."""
+    import contextlib
+    import ctypes as C
+    import io
+    import os
+    from fly_bproject_amd import _lib
+    from fly_bproject_amd.ppo import PPO
+    from tests.hip_helpers import make_args
+    lib = _lib.load()
+    lib.flyhip_debug_set_fwd_bwd_consumer_shift.argtypes = [C.c_int]
+    lib.flyhip_debug_set_fwd_bwd_consumer_shift.restype = None
+    os.environ["FLY_FWD_BWD_HANDOFF"] = "xcd"
+    try:
+        res = {}
+        for tag in ("clean", "broken"):
+            torch.manual_seed(0)
+            out = io.StringIO()
+            with contextlib.redirect_stdout(out):
+                agent = PPO(make_args(4096))
+                pol = agent.policy
+                assert pol.fuse_fwd_bwd and pol.handoff == "xcd"
+                for _ in range(agent.rollout_size - 1):
+                    agent.run()
+                if tag == "broken":
+                    # device-level check first: one poisoned minibatch + Adam leaves everything untouched
+                    lib.flyhip_debug_set_fwd_bwd_consumer_shift(1)
+                    before = (pol.P.clone(), pol.exp_avg.clone(), pol.exp_avg_sq.clone(), int(pol.step.item()))
+                    rows = agent.mini_chunk_size * 4096
+                    pol.minibatch_grad(agent.all_obs[:agent.mini_chunk_size].view(rows, 73),
+                                       agent.all_acts[:agent.mini_chunk_size].view(rows, 18),
+                                       agent.all_log_prob[:agent.mini_chunk_size].view(rows),
+                                       agent.all_advantage[:agent.mini_chunk_size].view(rows),
+                                       agent._target[:agent.mini_chunk_size].view(rows), agent._action_var, 0.2, fuse_norm=True)
+                    pol.adam_step(norm_ready=True)
+                    torch.cuda.synchronize()
+                    assert int(pol.tile_wait_error.item()) == 2 and float(pol.G[76]) == 1.0
+                    assert torch.equal(pol.P, before[0]) and torch.equal(pol.exp_avg, before[1])
+                    assert torch.equal(pol.exp_avg_sq, before[2]) and int(pol.step.item()) == before[3]
+                    pol.steps_issued -= 1                     # that call was this test's, not the update's
+                    pol.tile_wait_error.zero_()
+                    # now the real thing: the update's first fused launch fails, the device refuses all 75 steps
+                agent.run()                                    # last env step of the rollout + update
+                lib.flyhip_debug_set_fwd_bwd_consumer_shift(0)
+            torch.cuda.synchronize()
+            assert agent.optim_step == 75 and int(pol.step.item()) == 75
+            if tag == "broken":
+                assert "redoing them with two launches" in out.getvalue()
+                assert not pol.fuse_fwd_bwd and pol.fused_launch_failures == 1
+            else:
+                assert pol.fuse_fwd_bwd
+            res[tag] = (pol.P.clone(), pol.exp_avg.clone(), pol.exp_avg_sq.clone(), agent.all_advantage.clone())
+            agent.exit()
+        for a, b in zip(res["clean"], res["broken"]):
+            assert torch.equal(a, b)
+    finally:
+        lib.flyhip_debug_set_fwd_bwd_consumer_shift(0)
+        os.environ.pop("FLY_FWD_BWD_HANDOFF", None)
