@@ -47,6 +47,12 @@ SYMBOLS = {
     "mlp_adam_step": [_P] * 10 + [_F, _F, _F, _F, _F, _F, _P, _I, _P, _P, _P, _P, _P],
     "dqn_eps_greedy": [_P, _P, _P, _F, _I, _P, _L, _P],
     "dqn_huber_td": [_P, _P, _P, _P, _P, _F, _I, _L, _P, _P, _P],
+    "dqn_forward": [_P, _P, _P, _L, _P, _P],
+    "dqn_act": [_P, _P, _P, _L, _P, _P, _F, _P, _P, _P],
+    "dqn_td_step": [_P] * 10 + [_L, _F, _F] + [_P] * 7,
+    "dqn_grad_workspace_floats": [],
+    "dqn_grad_w": [_P] * 6 + [_L, _P, _P, _I, _P],
+    "dqn_adam_soft_update": [_P] * 12 + [_F, _F, _F, _F, _F, _P],
 }
 
 
@@ -73,7 +79,7 @@ def load():
     for name, argtypes in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
         fn.argtypes = argtypes
-        fn.restype = C.c_int64 if name == "mlp_grad_workspace_floats" else C.c_int
+        fn.restype = C.c_int64 if name.endswith("_workspace_floats") else C.c_int
     _lib = lib
     return lib
 

@@ -26,6 +26,23 @@ extern "C" hipError_t flyhip_launch_mlp_backward_dx(const float* PT, const float
                                                     const float* var, int64_t n, float inv_batch, float clip,
                                                     float* dz4, float* dz3, float* dz2, float* dz1, float* loss_part,
                                                     const uint16_t* PTB, void* stream);
+extern "C" hipError_t flyhip_launch_dqn_forward(const float* P, const float* PF, const float* x, int64_t n, float* q_out,
+                                                void* stream);
+extern "C" hipError_t flyhip_launch_dqn_act(const float* P, const float* PF, const float* x, int64_t n, const float* coin_u,
+                                            const float* rand_u, float epsilon, float* act_out, float* q_out, void* stream);
+extern "C" hipError_t flyhip_launch_dqn_td(const float* P, const float* PF, const float* PT, const float* P_tgt,
+                                           const float* PF_tgt, const float* obs, const float* next_obs, const float* act,
+                                           const float* reward, const float* done, int64_t n, float discount, float inv_B,
+                                           float* h1, float* h2, float* dz3, float* dz2, float* dz1, float* loss_part,
+                                           void* stream);
+extern "C" int64_t flyhip_dqn_grad_workspace_floats(void);
+extern "C" hipError_t flyhip_launch_dqn_grad_w(const float* x, const float* h1, const float* h2, const float* dz1,
+                                               const float* dz2, const float* dz3, int64_t n, float* workspace, float* grad,
+                                               int accumulate, void* stream);
+extern "C" hipError_t flyhip_launch_dqn_adam(float* P, float* PF, float* PT, float* P_tgt, float* PF_tgt, const int* idx_f,
+                                             const int* idx_t, const float* G, const float* mask, float* m, float* v,
+                                             int* step, float lr, float beta1, float beta2, float eps, float tau,
+                                             void* stream);
 extern "C" int64_t flyhip_mlp_grad_workspace_floats(void);
 extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, const float* h2, const float* h3,
                                                const float* dz1, const float* dz2, const float* dz3, const float* dz4,
@@ -387,6 +404,67 @@ int dqn_huber_td(const float* q_table, const float* act, const float* reward, co
     if (B <= 0 || A < 2) return fail(FLY_E_ARG, "dqn_huber_td: need B > 0 and A >= 2");
     hipError_t e = flyhip_launch_dqn_huber_td(q_table, act, reward, q_next, done, discount, A, B, dq, loss_part, stream);
     if (e != hipSuccess) return hip_fail(e, "dqn_huber_td launch");
+    return FLY_OK;
+}
+
+int dqn_forward(const float* params, const float* params_frag, const float* x, int64_t n, float* q_out, void* stream)
+{
+    if (!params || !params_frag || !x || !q_out) return fail(FLY_E_ARG, "dqn_forward: null pointer");
+    if (n <= 0) return fail(FLY_E_ARG, "dqn_forward: n must be > 0");
+    hipError_t e = flyhip_launch_dqn_forward(params, params_frag, x, n, q_out, stream);
+    if (e != hipSuccess) return hip_fail(e, "dqn_forward launch");
+    return FLY_OK;
+}
+
+int dqn_act(const float* params, const float* params_frag, const float* x, int64_t n, const float* coin_u,
+            const float* rand_u, float epsilon, float* act_out, float* q_out, void* stream)
+{
+    if (!params || !params_frag || !x || !coin_u || !rand_u || !act_out) return fail(FLY_E_ARG, "dqn_act: null pointer");
+    if (n <= 0) return fail(FLY_E_ARG, "dqn_act: n must be > 0");
+    hipError_t e = flyhip_launch_dqn_act(params, params_frag, x, n, coin_u, rand_u, epsilon, act_out, q_out, stream);
+    if (e != hipSuccess) return hip_fail(e, "dqn_act launch");
+    return FLY_OK;
+}
+
+int dqn_td_step(const float* params, const float* params_frag, const float* params_t_frag,
+                const float* target_params, const float* target_params_frag, const float* obs,
+                const float* next_obs, const float* act, const float* reward, const float* done, int64_t n,
+                float discount, float inv_B, float* h1, float* h2, float* dz3, float* dz2, float* dz1,
+                float* loss_part, void* stream)
+{
+    if (!params || !params_frag || !params_t_frag || !target_params || !target_params_frag || !obs || !next_obs || !act ||
+        !reward || !done || !h1 || !h2 || !dz3 || !dz2 || !dz1 || !loss_part)
+        return fail(FLY_E_ARG, "dqn_td_step: null pointer");
+    if (n <= 0) return fail(FLY_E_ARG, "dqn_td_step: n must be > 0");
+    hipError_t e = flyhip_launch_dqn_td(params, params_frag, params_t_frag, target_params, target_params_frag, obs, next_obs,
+                                        act, reward, done, n, discount, inv_B, h1, h2, dz3, dz2, dz1, loss_part, stream);
+    if (e != hipSuccess) return hip_fail(e, "dqn_td_step launch");
+    return FLY_OK;
+}
+
+int64_t dqn_grad_workspace_floats(void) { return flyhip_dqn_grad_workspace_floats(); }
+
+int dqn_grad_w(const float* x, const float* h1, const float* h2, const float* dz1, const float* dz2,
+               const float* dz3, int64_t n, float* workspace, float* grad, int32_t accumulate, void* stream)
+{
+    if (!x || !h1 || !h2 || !dz1 || !dz2 || !dz3 || !workspace || !grad) return fail(FLY_E_ARG, "dqn_grad_w: null pointer");
+    if (n <= 0) return fail(FLY_E_ARG, "dqn_grad_w: n must be > 0");
+    hipError_t e = flyhip_launch_dqn_grad_w(x, h1, h2, dz1, dz2, dz3, n, workspace, grad, accumulate, stream);
+    if (e != hipSuccess) return hip_fail(e, "dqn_grad_w launch");
+    return FLY_OK;
+}
+
+int dqn_adam_soft_update(float* params, float* params_frag, float* params_t_frag, float* target_params,
+                         float* target_params_frag, const int32_t* idx_frag, const int32_t* idx_t_frag,
+                         const float* grad, const float* mask, float* exp_avg, float* exp_avg_sq, int32_t* step,
+                         float lr, float beta1, float beta2, float eps, float tau, void* stream)
+{
+    if (!params || !params_frag || !params_t_frag || !target_params || !target_params_frag || !idx_frag || !idx_t_frag ||
+        !grad || !mask || !exp_avg || !exp_avg_sq || !step)
+        return fail(FLY_E_ARG, "dqn_adam_soft_update: null pointer");
+    hipError_t e = flyhip_launch_dqn_adam(params, params_frag, params_t_frag, target_params, target_params_frag, idx_frag,
+                                          idx_t_frag, grad, mask, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, tau, stream);
+    if (e != hipSuccess) return hip_fail(e, "dqn_adam_soft_update launch");
     return FLY_OK;
 }
 

@@ -3,11 +3,18 @@ configs[4]) on the MI355X-native Fly environment.
 
 Same structure and hyper-parameters as the reference (`Net` 3-layer LeakyReLU Q-network, Adam
 3e-4, discount 0.99, soft target update tau 0.995, eps = max(0.01, 0.8 - 0.01*step/20), a batch of
-128 stored steps x num_envs rows per update).  What the reference does with Python loops runs in
-two HIP kernels behind the C ABI: `dqn_eps_greedy` (its per-env argmax loop, dqn.py:94-96) and
-`dqn_huber_td` (TD target + Huber loss + the loss gradient at the Q table, dqn.py:68-79).  The
-replay is an HBM-resident ring of whole steps (`[capacity, N, .]` tensors) instead of a Python
-deque of tuples; a sample is an index_select of 128 step slots.
+128 stored steps x num_envs rows per update).  Everything on its hot path is hand-written HIP behind the C
+ABI (csrc/dqn_mfma.hip, fp32 MFMA):
+  * `act`      ONE launch per env step: Q-network forward + per-env first-argmax + eps-greedy mix
+               (`dqn_act`; dqn.py:89-100, a per-env Python loop upstream);
+  * `update`   per sampled replay step ONE launch for q_target(next_obs).max, q(obs), TD target, Huber
+               loss, its gradient and the backward chain (`dqn_td_step`), one for dW (`dqn_grad_w`,
+               accumulating over the sampled steps), and ONE launch for Adam + the soft target update
+               (`dqn_adam_soft_update`; dqn.py:64-85);
+  * the replay is an HBM-resident ring of whole steps (`[capacity, N, .]` tensors) instead of a Python
+    deque of tuples, and a sample is a list of ring SLOTS: the kernels read the rows where they lie,
+    nothing is gathered, concatenated or shuffled (the shuffle of replay.py:22 cannot change a mean).
+`Net` stays a torch module whose parameters are views into the packed buffers (checkpoints, tests).
 
 The upstream file is stale against the current `Fly` and cannot run as written; the two repairs
 are explicit:
@@ -16,6 +23,7 @@ are explicit:
       the scalar is broadcast to all 18 DoFs.
 """
 import ctypes as C
+import random
 
 import torch
 import torch.nn as nn
@@ -23,6 +31,40 @@ import torch.nn as nn
 from . import _lib
 from .fly import Fly
 from .params import NUM_DOF
+
+IN, IN_PAD, H, OUT, NACT = 73, 80, 256, 32, 18
+OFF_W1 = 0
+OFF_B1 = OFF_W1 + H * IN_PAD
+OFF_W2 = OFF_B1 + H
+OFF_B2 = OFF_W2 + H * H
+OFF_W3 = OFF_B2 + H
+OFF_B3 = OFF_W3 + OUT * H
+PACKED = OFF_B3 + OUT                       # 94752 (csrc/dqn_layout.h)
+OFF_F1, OFF_F2, OFF_F3 = 0, H * IN_PAD, H * IN_PAD + H * H
+FRAG = OFF_F3 + OUT * H                     # 94208
+OFF_T3, OFF_T2 = 0, H * OUT
+FRAG_T = OFF_T2 + H * H                     # 73728
+
+
+def build_index_maps():
+    """int32 [PACKED] maps master index -> position in the forward / transposed fragment copies (-1: none)."""
+    import numpy as np
+    from .policy import _frag_index
+    idx_f = np.full(PACKED, -1, np.int32)
+    idx_t = np.full(PACKED, -1, np.int32)
+    for off_w, N, K, off_f in ((OFF_W1, H, IN_PAD, OFF_F1), (OFF_W2, H, H, OFF_F2)):
+        n, k = np.meshgrid(np.arange(N), np.arange(K), indexing="ij")
+        idx_f[off_w + n * K + k] = off_f + _frag_index(n, k, K)
+    n, k = np.meshgrid(np.arange(OUT), np.arange(H), indexing="ij")
+    w, h, kq, q = k // 64, (k % 64) // 32, (k % 32) // 4, k % 4           # layer 3 forward: split-K over the four waves
+    idx_f[OFF_W3 + n * H + k] = OFF_F3 + ((w * 8 + kq) * 64 + (h * 32 + n)) * 4 + q
+    idx_t[OFF_W3 + n * H + k] = OFF_T3 + _frag_index(k, n, OUT)           # W3^T: 256 outputs, 32 reduced
+    n, k = np.meshgrid(np.arange(H), np.arange(H), indexing="ij")
+    idx_t[OFF_W2 + n * H + k] = OFF_T2 + _frag_index(k, n, H)             # W2^T
+    for idx, size in ((idx_f, FRAG), (idx_t, FRAG_T)):
+        used = idx[idx >= 0]
+        assert len(np.unique(used)) == len(used) == size and used.max() == size - 1
+    return idx_f, idx_t
 
 
 class Net(nn.Module):
@@ -52,7 +94,7 @@ class ReplayBuffer:
 
     DEFAULT_STEPS = 512
 
-    def __init__(self, num_envs, num_obs, device, buffer_limit=None, budget_bytes=32 << 30):
+    def __init__(self, num_envs, num_obs, device, buffer_limit=None, budget_bytes=32 << 30, seed=0):
         per_step = num_envs * (2 * num_obs + 3) * 4
         want = self.DEFAULT_STEPS if buffer_limit is None else int(buffer_limit)
         self.capacity = max(2, min(want, budget_bytes // per_step))
@@ -66,25 +108,80 @@ class ReplayBuffer:
         self.done = torch.empty((c, n), device=device)
         self.head = 0
         self.count = 0
-        self._gen = torch.Generator(device=device)
-        self._gen.manual_seed(0)
+        self._rng = random.Random(seed)                     # replay.py:19 uses random.sample: a HOST draw, no device sync
 
-    def push(self, obs, action, reward, next_obs, done):
+    def slot(self):
+        """The ring slot the next step goes to: `(obs, action, reward, next_obs, done)` row views the
+        caller (or a kernel) writes in place; `commit()` then publishes it."""
         h = self.head
-        self.obs[h].copy_(obs); self.next_obs[h].copy_(next_obs)
-        self.action[h].copy_(action); self.reward[h].copy_(reward); self.done[h].copy_(done)
-        self.head = (h + 1) % self.capacity
+        return self.obs[h], self.action[h], self.reward[h], self.next_obs[h], self.done[h]
+
+    def commit(self):
+        self.head = (self.head + 1) % self.capacity
         self.count = min(self.count + 1, self.capacity)
 
+    def push(self, obs, action, reward, next_obs, done):
+        o, a, r, no, d = self.slot()
+        o.copy_(obs); no.copy_(next_obs); a.copy_(action); r.copy_(reward); d.copy_(done)
+        self.commit()
+
+    def sample_slots(self, mini_batch_size):
+        """`mini_batch_size` distinct stored steps (replay.py:19)."""
+        return self._rng.sample(range(self.count), mini_batch_size)
+
     def sample(self, mini_batch_size):
-        """`mini_batch_size` distinct stored steps, all envs of each (replay.py:18-28).  The row
-        shuffle upstream applies afterwards does not change a mean over the whole batch and is skipped."""
-        idx = torch.randperm(self.count, device=self.obs.device, generator=self._gen)[:mini_batch_size]
-        f = lambda t: t.index_select(0, idx).flatten(0, 1)   # noqa: E731
-        return f(self.obs), f(self.action), f(self.reward), f(self.next_obs), f(self.done)
+        """A list of per-step chunks `(obs [N,73], act [N], reward [N], next_obs [N,73], done [N])`: views of the
+        ring, nothing is copied.  (replay.py:22-28 concatenates and shuffles the rows; neither changes the
+        batch mean the update computes.)"""
+        return [(self.obs[s], self.action[s], self.reward[s], self.next_obs[s], self.done[s])
+                for s in self.sample_slots(mini_batch_size)]
 
     def size(self):
         return self.count
+
+
+class QNetPacked:
+    """The packed Q-network pair (online + target) of csrc/dqn_layout.h with the fragment-ordered copies the
+    kernels stream; `net` / `net_target` parameters are re-pointed at strided views of the packed buffers."""
+
+    def __init__(self, net, net_target, device):
+        import numpy as np
+        self.device = torch.device(device)
+        z = lambda k: torch.zeros(k, dtype=torch.float32, device=self.device)   # noqa: E731
+        self.P, self.PF, self.PT = z(PACKED), z(FRAG), z(FRAG_T)
+        self.P_tgt, self.PF_tgt = z(PACKED), z(FRAG)
+        idx_f, idx_t = build_index_maps()
+        self.idx_f = torch.from_numpy(idx_f).to(self.device)
+        self.idx_t = torch.from_numpy(idx_t).to(self.device)
+        self._src_f = torch.nonzero(self.idx_f >= 0).squeeze(-1); self._dst_f = self.idx_f[self._src_f].long()
+        self._src_t = torch.nonzero(self.idx_t >= 0).squeeze(-1); self._dst_t = self.idx_t[self._src_t].long()
+        mask = np.zeros(PACKED, np.float32)
+        for buf, module in ((self.P, net), (self.P_tgt, net_target)):
+            views = {"net.0.weight": buf[OFF_W1:OFF_B1].view(H, IN_PAD)[:, :IN], "net.0.bias": buf[OFF_B1:OFF_W2],
+                     "net.2.weight": buf[OFF_W2:OFF_B2].view(H, H), "net.2.bias": buf[OFF_B2:OFF_W3],
+                     "net.4.weight": buf[OFF_W3:OFF_B3].view(OUT, H)[:NACT], "net.4.bias": buf[OFF_B3:OFF_B3 + NACT]}
+            params = dict(module.named_parameters())
+            assert set(params) == set(views), "Net does not have the reference's parameter set"
+            with torch.no_grad():
+                for k, view in views.items():
+                    view.copy_(params[k].data.to(self.device))
+                    params[k].data = view
+            if buf is self.P:
+                for view in views.values():
+                    idx = torch.arange(PACKED).as_strided(view.shape, view.stride(), view.storage_offset())
+                    mask[idx.reshape(-1).numpy()] = 1.0
+        self.grad_mask = torch.from_numpy(mask).to(self.device)
+        assert int(mask.sum()) == IN * H + H + H * H + H + NACT * H + NACT
+        self.G, self.exp_avg, self.exp_avg_sq = z(PACKED), z(PACKED), z(PACKED)
+        self.step = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.refresh()
+
+    def refresh(self):
+        """Rebuild the fragment copies from the packed masters (after a load / out-of-band change)."""
+        with torch.no_grad():
+            self.PF[self._dst_f] = self.P[self._src_f]
+            self.PT[self._dst_t] = self.P[self._src_t]
+            self.PF_tgt[self._dst_f] = self.P_tgt[self._src_f]
 
 
 class DQN:
@@ -106,14 +203,16 @@ class DQN:
         if cap is None:
             cap = max(4 * self.mini_batch_size, 64)                       # stated default: 4 samples' worth of steps
         self.replay = ReplayBuffer(n, self.env.num_obs, dev, buffer_limit=cap,
-                                   budget_bytes=int(getattr(args, "replay_bytes", 32 << 30)))
+                                   budget_bytes=int(getattr(args, "replay_bytes", 32 << 30)),
+                                   seed=int(getattr(args, "seed", 0)))
         print("replay capacity: %d steps x %d envs = %.2f GB of HBM" % (self.replay.capacity, n, self.replay.bytes / 1e9))
         self.q = Net(self.env.num_obs, self.act_space).to(dev)            # D1
         self.q_target = Net(self.env.num_obs, self.act_space).to(dev)
-        soft_update(self.q, self.q_target, tau=0.0)
+        soft_update(self.q, self.q_target, tau=0.0)                       # dqn.py:60
         self.q_target.eval()
-        self.optimizer = torch.optim.Adam(self.q.parameters(), lr=self.lr)
         self._lib = _lib.load()
+        self.packed = QNetPacked(self.q, self.q_target, dev)
+        self._alloc_workspace(n)
         self._gen = torch.Generator(device=dev)
         self._gen.manual_seed(int(getattr(args, "seed", 0)))
         self._coin = torch.empty(n, device=dev)
@@ -121,71 +220,93 @@ class DQN:
         self._score_acc = torch.zeros((), device=dev)
         self.last_loss = None
 
-    def td_loss_and_grad(self, q_table, act, reward, q_next, done_mask):
-        """dqn.py:71-78 through `dqn_huber_td`: returns (loss scalar tensor, dLoss/dQ [B, A])."""
-        B, A = q_table.shape
-        dq = torch.empty_like(q_table)
-        parts = torch.empty((B + 255) // 256, device=q_table.device)
-        p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
-        _lib.check(self._lib.dqn_huber_td(p(q_table), p(act), p(reward), p(q_next), p(done_mask),
-                                          C.c_float(self.discount), C.c_int(A), C.c_int64(B), p(dq), p(parts),
-                                          _lib.stream_ptr()), "dqn_huber_td")
-        return parts.sum() / B, dq
+    def _alloc_workspace(self, rows):
+        """Saved activations / gradients of ONE sampled step (the update walks the sampled steps one by one)."""
+        dev = self.device
+        r = (int(rows) + 31) // 32 * 32
+        e = lambda c: torch.empty(r, c, device=dev)   # noqa: E731
+        self._ws_rows = r
+        self._h1, self._h2, self._dz1, self._dz2, self._dz3 = e(H), e(H), e(H), e(H), e(OUT)
+        self._gw_ws = torch.empty(int(self._lib.dqn_grad_workspace_floats()), device=dev)
+        self._loss_part = torch.zeros(r // 32, device=dev)
+        self._loss_acc = torch.zeros((), device=dev)
 
-    def update(self):
-        """dqn.py:64-85."""
-        self.optimizer.zero_grad()
-        obs, act, reward, next_obs, done_mask = self.replay.sample(self.mini_batch_size)
-        q_table = self.q(obs)
-        with torch.no_grad():
-            q_next = self.q_target(next_obs)
-            loss, dq = self.td_loss_and_grad(q_table.detach().contiguous(), act.contiguous(), reward.contiguous(),
-                                             q_next.contiguous(), done_mask.contiguous())
-        q_table.backward(dq)
-        self.optimizer.step()
-        soft_update(self.q, self.q_target, self.tau)
-        return loss
+    def update(self, chunks=None):
+        """dqn.py:64-85.  `chunks` (tests) = a list of `(obs, act, reward, next_obs, done_mask)` row blocks that
+        together form the batch; default: `mini_batch_size` sampled steps of the replay ring."""
+        if chunks is None:
+            chunks = self.replay.sample(self.mini_batch_size)
+        pk, lib = self.packed, self._lib
+        p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+        st = _lib.stream_ptr()
+        B = sum(int(c[0].shape[0]) for c in chunks)
+        inv_B = 1.0 / float(B)
+        self._loss_acc.zero_()
+        for i, (obs, act, reward, next_obs, done_mask) in enumerate(chunks):
+            n = int(obs.shape[0])
+            if n > self._ws_rows:
+                self._alloc_workspace(n)
+            for t in (obs, act, reward, next_obs, done_mask):
+                assert t.is_contiguous() and t.dtype == torch.float32
+            _lib.check(lib.dqn_td_step(p(pk.P), p(pk.PF), p(pk.PT), p(pk.P_tgt), p(pk.PF_tgt), p(obs), p(next_obs), p(act),
+                                       p(reward), p(done_mask), C.c_int64(n), C.c_float(self.discount), C.c_float(inv_B),
+                                       p(self._h1), p(self._h2), p(self._dz3), p(self._dz2), p(self._dz1), p(self._loss_part),
+                                       st), "dqn_td_step")
+            _lib.check(lib.dqn_grad_w(p(obs), p(self._h1), p(self._h2), p(self._dz1), p(self._dz2), p(self._dz3), C.c_int64(n),
+                                      p(self._gw_ws), p(pk.G), C.c_int(1 if i else 0), st), "dqn_grad_w")
+            self._loss_acc += self._loss_part[: (n + 31) // 32].sum()
+        _lib.check(lib.dqn_adam_soft_update(p(pk.P), p(pk.PF), p(pk.PT), p(pk.P_tgt), p(pk.PF_tgt), p(pk.idx_f), p(pk.idx_t),
+                                            p(pk.G), p(pk.grad_mask), p(pk.exp_avg), p(pk.exp_avg_sq), p(pk.step),
+                                            C.c_float(self.lr), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8),
+                                            C.c_float(self.tau), st), "dqn_adam_soft_update")
+        return self._loss_acc * inv_B                                     # F.smooth_l1_loss: mean over the batch
+
+    def q_parameters(self):
+        return list(self.q.parameters())
+
+    def q_values(self, obs):
+        """Q table f32 [n,18] of `obs` through the MFMA forward (dqn.py:28)."""
+        x = obs.reshape(-1, IN)
+        x = x if x.is_contiguous() else x.contiguous()
+        out = torch.empty((x.shape[0], NACT), device=self.device)
+        p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+        _lib.check(self._lib.dqn_forward(p(self.packed.P), p(self.packed.PF), p(x), C.c_int64(x.shape[0]), p(out),
+                                         _lib.stream_ptr()), "dqn_forward")
+        return out
 
     def act(self, obs, epsilon=0.0):
-        """dqn.py:89-100: one scalar in [-1,1] per env."""
+        """dqn.py:89-100: one scalar in [-1,1] per env, in one launch."""
         n = obs.shape[0]
-        self._coin.uniform_(generator=self._gen)
+        self._coin.uniform_(generator=self._gen)                         # the two draws of dqn.py:90-92, in order
         self._rand.uniform_(generator=self._gen)
-        with torch.no_grad():
-            q_table = self.q(obs).contiguous()
+        x = obs if obs.is_contiguous() else obs.contiguous()
         out = torch.empty(n, device=obs.device)
         p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
-        _lib.check(self._lib.dqn_eps_greedy(p(q_table), p(self._coin), p(self._rand), C.c_float(epsilon),
-                                            C.c_int(self.act_space), p(out), C.c_int64(n), _lib.stream_ptr()),
-                   "dqn_eps_greedy")
+        _lib.check(self._lib.dqn_act(p(self.packed.P), p(self.packed.PF), p(x), C.c_int64(n), p(self._coin), p(self._rand),
+                                     C.c_float(epsilon), p(out), None, _lib.stream_ptr()), "dqn_act")
         return out
 
     def run(self):
         """dqn.py:102-126."""
         epsilon = max(0.01, 0.8 - 0.01 * (self.run_step / 20))
-        obs = self.env.obs_buf.clone()
-        action = self.act(obs, epsilon)
-        self.env.step(action.unsqueeze(-1).expand(-1, NUM_DOF).contiguous())     # D2
-        next_obs, reward, done = self.env.obs_buf.clone(), self.env.reward_buf.clone(), self.env.reset_buf.clone()
+        obs_row, act_row, rew_row, next_row, done_row = self.replay.slot()       # the step is recorded where it will live
+        obs_row.copy_(self.env.obs_buf)                                          # dqn.py:106
+        act_row.copy_(self.act(obs_row, epsilon))
+        self.env.step(act_row.unsqueeze(-1).expand(-1, NUM_DOF).contiguous())    # D2
+        next_row.copy_(self.env.obs_buf); rew_row.copy_(self.env.reward_buf)     # dqn.py:109
+        torch.sub(1.0, self.env.reset_buf, out=done_row)                         # 1 - done (dqn.py:113), BEFORE the reset clears it
         self.env.reset_async()                                                   # dqn.py:110
-        self.replay.push(obs, action, reward, next_obs, (1 - done).to(torch.float32))
+        self.replay.commit()
         if self.replay.size() > self.mini_batch_size:
             loss = self.update()
             self.last_loss = loss
-            self._score_acc += reward.mean() / self.num_eval_freq
+            self._score_acc += rew_row.mean() / self.num_eval_freq
             if self.run_step % self.num_eval_freq == 0:
                 self.score = float(self._score_acc.item()); self._score_acc.zero_()
                 print('Steps: {:04d} | Reward {:.04f} | TD Loss {:.04f} Epsilon {:.04f} Buffer {:03d}'
                       .format(self.run_step, self.score, float(loss.item()), epsilon, self.replay.size()))
                 self.score = 0
         self.run_step += 1
-
-    def q_parameters(self):
-        return list(self.q.parameters())
-
-    def q_values(self, obs):
-        with torch.no_grad():
-            return self.q(obs).contiguous()
 
     def exit(self):
         self.env.exit()

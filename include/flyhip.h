@@ -338,6 +338,48 @@ int dqn_huber_td(const float* q_table, const float* act, const float* reward, co
                  const float* done, float discount, int32_t A, int64_t B, float* dq, float* loss_part,
                  void* stream);
 
+/*
+ * DQN variant on the matrix cores: the Q-network of UselessFiles/dqn.py:17-29 (73 -> 256 -> 256 -> 18, LeakyReLU;
+ * D1: num_obs is the environment's 73) as packed parameters in the layout of csrc/dqn_layout.h
+ * (DQN_PACKED_FLOATS_ABI floats; `params_frag` / `params_t_frag` = its fragment-ordered copies of
+ * DQN_FRAG_FLOATS_ABI / DQN_FRAG_T_FLOATS_ABI floats).  fp32 MFMA arithmetic.
+ *   dqn_forward   : q_out f32 [n][18] = Net(x), x f32 [n][73]                                   (dqn.py:28)
+ *   dqn_act       : dqn.py:89-100 in ONE launch: Net(x), per row the FIRST maximal entry -> idx/17, mixed
+ *                   with rand_u where coin_u < epsilon, mapped to [-1,1]; act_out f32 [n]; q_out optional.
+ *   dqn_td_step   : dqn.py:64-79 for ONE sampled replay step (n rows, pointers straight into the replay
+ *                   ring: no gather): q_target(next_obs).max(1), q(obs), target = reward + discount * max *
+ *                   done, smooth_l1 (loss_part f32 [ceil(n/32)]: per-tile sums of the Huber terms), its
+ *                   gradient at the Q table scaled by inv_B (1 / rows of the WHOLE batch), and the backward
+ *                   chain down to the first layer's pre-activations.  Leaves h1, h2, dz1, dz2 f32 [n32][256]
+ *                   and dz3 f32 [n32][32] (n32 = n rounded up to 32; tile-fragment order) for dqn_grad_w.
+ *   dqn_grad_w    : dW / db of the three layers from those tensors into `grad` (packed layout);
+ *                   accumulate != 0 adds to `grad` (one call per sampled step of a batch).  `workspace`
+ *                   holds dqn_grad_workspace_floats() floats.
+ *   dqn_adam_soft_update : dqn.py:81-84: Adam (torch defaults, no clipping) on `params` with the refresh
+ *                   of its fragment copies, then target = target * tau + params * (1 - tau)
+ *                   (dqn.py:33-36) with the target's forward fragment copy.  `mask` (packed, 0/1) freezes
+ *                   padding; `step` device int counter; idx_* int32 [DQN_PACKED_FLOATS_ABI] (-1: no copy).
+ */
+#define DQN_PACKED_FLOATS_ABI 94752
+#define DQN_FRAG_FLOATS_ABI 94208
+#define DQN_FRAG_T_FLOATS_ABI 73728
+int dqn_forward(const float* params, const float* params_frag, const float* x, int64_t n, float* q_out, void* stream);
+int dqn_act(const float* params, const float* params_frag, const float* x, int64_t n, const float* coin_u,
+            const float* rand_u, float epsilon, float* act_out, float* q_out, void* stream);
+int dqn_td_step(const float* params, const float* params_frag, const float* params_t_frag,
+                const float* target_params, const float* target_params_frag, const float* obs,
+                const float* next_obs, const float* act, const float* reward, const float* done, int64_t n,
+                float discount, float inv_B, float* h1, float* h2, float* dz3, float* dz2, float* dz1,
+                float* loss_part, void* stream);
+int64_t dqn_grad_workspace_floats(void);
+int dqn_grad_w(const float* x, const float* h1, const float* h2, const float* dz1, const float* dz2,
+               const float* dz3, int64_t n, float* workspace, float* grad, int32_t accumulate, void* stream);
+int dqn_adam_soft_update(float* params, float* params_frag, float* params_t_frag, float* target_params,
+                         float* target_params_frag, const int32_t* idx_frag, const int32_t* idx_t_frag,
+                         const float* grad, const float* mask, float* exp_avg, float* exp_avg_sq, int32_t* step,
+                         float lr, float beta1, float beta2, float eps, float tau, void* stream);
+
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,30 +63,134 @@ def test_hip_huber_td_vs_reference_and_oracle(golden):
     np.testing.assert_allclose(dq.cpu().numpy(), dq2, rtol=3e-7, atol=0)     # d/B vs d*(1/B): one ulp
 
 
+def _bare_dqn(golden_sd=None, rows=384):
+    """A DQN without an environment: the packed Q-network pair + workspace on cuda:0."""
+    from fly_bproject_amd import _lib
+    from fly_bproject_amd.dqn import DQN, Net, QNetPacked, soft_update
+    d = DQN.__new__(DQN)
+    d.device = torch.device("cuda:0")
+    d.discount, d.mini_batch_size, d.tau, d.act_space, d.lr = 0.99, 4, 0.995, 18, 3e-4
+    d.q, d.q_target = Net(73, 18).to("cuda:0"), Net(73, 18).to("cuda:0")
+    if golden_sd is not None:
+        d.q.load_state_dict(golden_sd)
+    soft_update(d.q, d.q_target, tau=0.0)
+    d._lib = _lib.load()
+    d.packed = QNetPacked(d.q, d.q_target, "cuda:0")
+    d._alloc_workspace(rows)
+    return d
+
+
 @pytest.mark.gpu
-def test_dqn_update_matches_reference_step(golden):
-    """One DQN.update from the reference's weights on the reference's batch: same loss, same
-    Q-network and target network afterwards (Adam 3e-4 + soft update 0.995)."""
-    from fly_bproject_amd.dqn import DQN, Net, soft_update
-    import types
+@pytest.mark.parametrize("n", [1, 33, 96, 4099])
+def test_mfma_q_network_forward_matches_torch(golden, n):
+    """dqn_forward (fp32 MFMA, packed fragment-ordered weights) against torch's fp32 evaluation of the same
+    module, on the reference's golden weights; ragged last tile included."""
     g = golden("g8_dqn")
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")   # noqa: E731
-    d = DQN.__new__(DQN)
-    d.discount, d.mini_batch_size, d.tau, d.act_space = 0.99, 4, 0.995, 18
-    d.q, d.q_target = Net(73, 18).to("cuda:0"), Net(73, 18).to("cuda:0")
-    d.q.load_state_dict({k[2:]: t(g[k]) for k in g.files if k.startswith("q_") and "." in k})
-    soft_update(d.q, d.q_target, tau=0.0)
-    d.optimizer = torch.optim.Adam(d.q.parameters(), lr=3e-4)
-    from fly_bproject_amd import _lib
-    d._lib = _lib.load()
+    d = _bare_dqn({k[2:]: t(g[k]) for k in g.files if k.startswith("q_") and "." in k})
+    torch.manual_seed(n)
+    x = torch.randn(n, 73, device="cuda:0") * 2
+    if n == 96:
+        x = t(g["obs"])
+    got = d.q_values(x)
+    with torch.no_grad():
+        h = torch.nn.functional.leaky_relu(x.double() @ d.q.net[0].weight.double().T + d.q.net[0].bias.double())
+        h = torch.nn.functional.leaky_relu(h @ d.q.net[2].weight.double().T + d.q.net[2].bias.double())
+        ref = h @ d.q.net[4].weight.double().T + d.q.net[4].bias.double()
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-5)
+    if n == 96:     # and the Q tables the reference recorded for these observations
+        np.testing.assert_allclose(got.cpu().numpy(), g["e08_q"], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("eps", [0.0, 0.8])
+def test_fused_act_equals_forward_plus_eps_greedy(golden, eps):
+    """dqn_act (forward + first-argmax + eps mix in one launch) == dqn_forward followed by the oracle's
+    dqn.py:89-100 on that Q table, bit for bit; ties resolve to the FIRST maximal entry."""
+    g = golden("g8_dqn")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")   # noqa: E731
+    d = _bare_dqn({k[2:]: t(g[k]) for k in g.files if k.startswith("q_") and "." in k})
+    n = 4099
+    torch.manual_seed(3)
+    x = torch.randn(n, 73, device="cuda:0")
+    x[7] = x[8]                                                   # identical rows -> identical actions
+    d._gen = torch.Generator(device="cuda:0"); d._gen.manual_seed(1)
+    d._coin = torch.empty(n, device="cuda:0"); d._rand = torch.empty(n, device="cuda:0")
+    a = d.act(x, eps)
+    q = d.q_values(x)
+    torch.cuda.synchronize()
+    ref = O.dqn_eps_greedy(q.cpu().numpy(), d._coin.cpu().numpy(), d._rand.cpu().numpy(), eps)
+    assert np.array_equal(a.cpu().numpy(), ref)
+    # a constant last layer makes every Q row a 18-way tie: index 0 must win
+    with torch.no_grad():
+        d.q.net[4].weight.zero_(); d.q.net[4].bias.fill_(0.25)
+    d.packed.refresh()
+    a0 = d.act(x, 0.0)
+    assert torch.all(a0 == -1.0)
+
+
+@pytest.mark.gpu
+def test_dqn_update_matches_reference_step(golden):
+    """One DQN.update from the reference's weights on the reference's batch, all on the HIP kernels
+    (dqn_td_step + dqn_grad_w + dqn_adam_soft_update): same loss, same Q-network and target network
+    afterwards (Adam 3e-4 + soft update 0.995) -- as ONE chunk and as four chunks whose gradients accumulate."""
+    g = golden("g8_dqn")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")   # noqa: E731
     batch = (t(g["b_obs"]), t(g["b_act"]), t(g["b_rew"]), t(g["b_next"]), t(g["b_done"]))
-    d.replay = types.SimpleNamespace(sample=lambda m: batch)
-    loss = d.update()
-    np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=2e-5)
-    for k, v in d.q.state_dict().items():
-        np.testing.assert_allclose(v.cpu().numpy(), g["q1_" + k], rtol=2e-4, atol=3e-5, err_msg=k)
-    for k, v in d.q_target.state_dict().items():
-        np.testing.assert_allclose(v.cpu().numpy(), g["qt1_" + k], rtol=2e-4, atol=1e-6, err_msg=k)
+    B = batch[0].shape[0]
+    for parts in (1, 4):
+        d = _bare_dqn({k[2:]: t(g[k]) for k in g.files if k.startswith("q_") and "." in k})
+        step = B // parts
+        chunks = [tuple(x[i * step:(i + 1) * step].contiguous() for x in batch) for i in range(parts)]
+        loss = d.update(chunks)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=2e-5)
+        assert int(d.packed.step) == 1
+        for k, v in d.q.state_dict().items():
+            np.testing.assert_allclose(v.cpu().numpy(), g["q1_" + k], rtol=2e-4, atol=3e-5, err_msg=k)
+        for k, v in d.q_target.state_dict().items():
+            np.testing.assert_allclose(v.cpu().numpy(), g["qt1_" + k], rtol=2e-4, atol=1e-6, err_msg=k)
+        # padding never moves, fragment copies follow the masters
+        assert torch.all(d.packed.P[:256 * 80].view(256, 80)[:, 73:] == 0)
+        pf, pt, pft = d.packed.PF.clone(), d.packed.PT.clone(), d.packed.PF_tgt.clone()
+        d.packed.refresh()
+        assert torch.equal(pf, d.packed.PF) and torch.equal(pt, d.packed.PT) and torch.equal(pft, d.packed.PF_tgt)
+
+
+@pytest.mark.gpu
+def test_dqn_td_gradient_matches_autograd():
+    """The packed gradient of one update batch (TD target from the target net, Huber, backward, dW) against
+    torch autograd on the same module in fp64-free fp32; random weights, 1000 rows (ragged tile)."""
+    torch.manual_seed(5)
+    d = _bare_dqn(rows=1000)
+    with torch.no_grad():
+        for p_ in d.q_target.parameters():
+            p_.add_(0.05 * torch.randn_like(p_))                 # target differs from online
+    d.packed.refresh()
+    B = 1000
+    obs = torch.randn(B, 73, device="cuda:0"); nxt = torch.randn(B, 73, device="cuda:0")
+    act = torch.rand(B, device="cuda:0") * 2 - 1
+    rew = torch.randn(B, device="cuda:0") * 2; done = (torch.rand(B, device="cuda:0") > 0.1).float()
+    q_table = d.q(obs)
+    idx = torch.round(0.5 * (act + 1) * 17).long()
+    q_val = q_table[torch.arange(B), idx]
+    with torch.no_grad():
+        target = rew + 0.99 * d.q_target(nxt).max(1)[0] * done
+    loss = torch.nn.functional.smooth_l1_loss(q_val, target)
+    grads = torch.autograd.grad(loss, list(d.q.parameters()))
+    before = d.packed.P.clone()
+    got_loss = d.update([(obs, act, rew, nxt, done)])
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(got_loss), float(loss), rtol=2e-5)
+    G = d.packed.G
+    views = {"net.0.weight": G[:256 * 80].view(256, 80)[:, :73], "net.0.bias": G[20480:20736],
+             "net.2.weight": G[20736:86272].view(256, 256), "net.2.bias": G[86272:86528],
+             "net.4.weight": G[86528:94720].view(32, 256)[:18], "net.4.bias": G[94720:94738]}
+    for (name, _), want in zip(d.q.named_parameters(), grads):
+        got = views[name]
+        scale = float(want.abs().max()) + 1e-12
+        assert float((got - want).abs().max()) <= 2e-4 * scale + 1e-9, name
+    assert not torch.equal(before, d.packed.P)
 
 
 @pytest.mark.gpu
@@ -94,13 +198,15 @@ def test_dqn_runs_end_to_end():
     from fly_bproject_amd.dqn import DQN
     from tests.hip_helpers import make_args
     torch.manual_seed(0)
-    agent = DQN(make_args(256, dqn_mini_batch_size=8, replay_bytes=64 << 20))
-    assert agent.replay.capacity >= 9
+    with contextlib.redirect_stdout(io.StringIO()):
+        agent = DQN(make_args(256, dqn_mini_batch_size=8, replay_steps=16))
+    assert agent.replay.capacity == 16
     with contextlib.redirect_stdout(io.StringIO()):
         for _ in range(30):
             agent.run()
     torch.cuda.synchronize()
-    assert agent.replay.size() == min(30, agent.replay.capacity) and agent.last_loss is not None
+    assert agent.replay.size() == 16 and agent.last_loss is not None       # the ring wrapped
+    assert int(agent.packed.step) == 30 - 8                                 # an update per step once size > 8
     assert torch.isfinite(agent.last_loss) and all(torch.isfinite(p).all() for p in agent.q.parameters())
     a = agent.act(agent.env.obs_buf, 0.0)
     assert a.shape == (256,) and float(a.abs().max()) <= 1.0

@@ -14,7 +14,7 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 mb = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 torch.manual_seed(0)
-agent = DQN(make_args(n, dqn_mini_batch_size=mb, replay_bytes=8 << 30))
+agent = DQN(make_args(n, dqn_mini_batch_size=mb, replay_steps=max(4 * mb, 64)))
 print("replay capacity (steps):", agent.replay.capacity, "batch rows per update:", agent.batch_size)
 t0 = time.perf_counter()
 for _ in range(steps):
