@@ -35,6 +35,10 @@ def parse():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_alt_gemm", action="store_true", help="skip the secondary bf16x3 measurement")
     ap.add_argument("--kernel_reps", type=int, default=200)
+    ap.add_argument("--workload", choices=["ppo", "dqn"], default="ppo",
+                    help="ppo (default, BASELINE's metric config) or dqn = BASELINE configs[4] (labelled line of its own)")
+    ap.add_argument("--dqn_envs", type=int, default=32768)
+    ap.add_argument("--dqn_mini_batch", type=int, default=128, help="sampled replay steps per update (dqn.py:49)")
     ap.add_argument("--dry_run", action="store_true",
                     help="rank plumbing only (spawn, rendezvous, barrier, max-over-ranks timing, the JSON line) with no "
                          "GPU work: what the CPU/gloo test of --gpus N exercises")
@@ -295,12 +299,79 @@ def dry_run(a):
         dist.destroy_process_group()
 
 
+DQN_FWD_FLOP = 2 * (73 * 256 + 256 * 256 + 256 * 18)            # 177 664 per sample
+DQN_BWD_DX_FLOP = 2 * (18 * 256 + 256 * 256)                     # 140 288
+
+
+def dqn_bench(a):
+    """BASELINE configs[4]: DQN, 32768 envs, HBM-resident replay ring (stated capacity), per-env eps-greedy and
+    Huber-TD on the HIP kernels.  A "step" = one DQN.run(): act (one launch), env step, record into the ring,
+    one update on `dqn_mini_batch` sampled steps x num_envs rows (dqn.py:102-126).  One rank (the reference DQN
+    has no data-parallel form and BASELINE names none)."""
+    import ctypes as C
+    from fly_bproject_amd import _lib
+    from fly_bproject_amd.dqn import DQN
+    if a.gpus != 1:
+        sys.exit("bench.py --workload dqn runs on one GPU")
+    torch.cuda.set_device(0)
+    torch.manual_seed(0)
+    n, mb = a.dqn_envs, a.dqn_mini_batch
+    cap = max(4 * mb, 64)
+    with quiet():
+        agent = DQN(make_args(n, dqn_mini_batch_size=mb, replay_steps=cap))
+        for _ in range(mb + a.warmup):                # fill the ring to the sample size (no updates yet), then `warmup` steps with updates
+            agent.run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with quiet():
+        for _ in range(a.steps):
+            agent.run()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert int(agent.packed.step.item()) == a.warmup + a.steps, "an update was skipped"
+    finite = all(torch.isfinite(p).all().item() for p in agent.q.parameters())
+    lib = _lib.load()
+    p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    pk, rp = agent.packed, agent.replay
+    st = _lib.stream_ptr()
+    t_td = _time_launches(lambda: lib.dqn_td_step(p(pk.P), p(pk.PF), p(pk.PT), p(pk.P_tgt), p(pk.PF_tgt), p(rp.obs[0]),
+                                                  p(rp.next_obs[0]), p(rp.action[0]), p(rp.reward[0]), p(rp.done[0]), n,
+                                                  C.c_float(0.99), C.c_float(1.0 / (n * mb)), p(agent._h1), p(agent._h2),
+                                                  p(agent._dz3), p(agent._dz2), p(agent._dz1), p(agent._loss_part), st),
+                          a.kernel_reps)
+    t_gw = _time_launches(lambda: lib.dqn_grad_w(p(rp.obs[0]), p(agent._h1), p(agent._h2), p(agent._dz1), p(agent._dz2),
+                                                 p(agent._dz3), n, p(agent._gw_ws), p(pk.G), 1, st), a.kernel_reps)
+    t_act = _time_launches(lambda: lib.dqn_act(p(pk.P), p(pk.PF), p(rp.obs[0]), n, p(agent._coin), p(agent._rand),
+                                               C.c_float(0.1), p(agent._dz3), None, st), a.kernel_reps)
+
+    def mfma(name, dur, flop, per_step):
+        ach = flop / dur / 1e12
+        return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5), "traffic": None, "avg_launch_us": round(dur * 1e6, 3),
+                "algorithmic_per_launch": flop, "launches_per_step": per_step, "step_share_ms": round(dur * per_step * 1e3, 3)}
+    ks = [mfma("dqn_td_kernel (target fwd + online fwd + Huber-TD + dX chain, %d rows)" % n, t_td,
+               (2 * DQN_FWD_FLOP + DQN_BWD_DX_FLOP) * n, mb),
+          mfma("dqn_grad_w_kernel (+reduce)", t_gw, DQN_FWD_FLOP * n, mb),
+          mfma("dqn_act_kernel (forward + argmax + eps-greedy)", t_act, DQN_FWD_FLOP * n, 1)]
+    agent.exit()
+    print(json.dumps({
+        "metric": "env-steps/sec (DQN act + env step + update), %d envs" % n, "value": round(n * a.steps / elapsed, 1),
+        "unit": "env-steps/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "fly_dqn_%denvs_batch%dsteps" % (n, mb), "num_envs_per_gpu": n, "sampled_steps_per_update": mb,
+                   "rows_per_update": n * mb, "replay_capacity_steps": rp.capacity, "replay_bytes": rp.bytes,
+                   "updates_per_env_step": 1, "parallelism": "dp1"},
+        "params_finite": finite, "roofline": ks[0], "kernels": ks[1:]}), flush=True)
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a))                    # before anything touches the GPU
     if a.dry_run:
         return dry_run(a)
+    if a.workload == "dqn":
+        return dqn_bench(a)
     from fly_bproject_amd.dist import broadcast_policy, init_from_env
     from fly_bproject_amd.ppo import PPO
 
