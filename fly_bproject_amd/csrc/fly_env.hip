@@ -23,6 +23,7 @@
 // tile and written as one contiguous 16x73 block per workgroup with 16-byte stores.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "flyhip.h"
 
 namespace {

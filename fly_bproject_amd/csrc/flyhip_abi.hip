@@ -84,7 +84,7 @@ extern "C" hipError_t flyhip_launch_rollout_bookkeeping(const float* reward, int
 extern "C" hipError_t flyhip_launch_rollout_step(const FlyConfig* dcfg, const FlyBuffers* b, const float* P, const float* PF,
                                                  const float* x, int64_t n, const float* eps, const float* var, int var_steps,
                                                  float var_decay, float var_min, float* act, float* logp, float* v_out,
-                                                 void* stream);
+                                                 const uint16_t* PB, void* stream);
 extern "C" hipError_t flyhip_launch_adv_stats(const float* adv, int64_t n, float* stats, void* stream);
 extern "C" hipError_t flyhip_launch_adv_apply(float* adv, int64_t n, const float* totals, float count, float eps, void* stream);
 
@@ -191,7 +191,7 @@ int fly_step(FlyHandle h, const float* actions, const FlyBuffers* b, void* strea
 
 int ppo_rollout_step(FlyHandle h, const FlyBuffers* b, const float* params, const float* params_frag, const float* x,
                      const float* eps, const float* var, int32_t var_steps, float var_decay, float var_min,
-                     float* act_out, float* logp_out, float* v_out, void* stream)
+                     float* act_out, float* logp_out, float* v_out, const uint16_t* params_b3, void* stream)
 {
     if (!h) return fail(FLY_E_ARG, "handle is null");
     if (!params || !params_frag || !x || !eps || !var || !act_out || !logp_out)
@@ -200,7 +200,7 @@ int ppo_rollout_step(FlyHandle h, const FlyBuffers* b, const float* params, cons
     int rc = check_buffers(b, PH_SCALE | PH_RESET | PH_INTEGRATE | PH_OBS | PH_PROGRESS | PH_REWARD);
     if (rc) return rc;
     hipError_t e = flyhip_launch_rollout_step(h->dev, b, params, params_frag, x, h->host.num_envs, eps, var, var_steps,
-                                              var_decay, var_min, act_out, logp_out, v_out, stream);
+                                              var_decay, var_min, act_out, logp_out, v_out, params_b3, stream);
     if (e != hipSuccess) return hip_fail(e, "ppo_rollout_step launch");
     return FLY_OK;
 }

@@ -20,6 +20,7 @@
 // output columns.  DESIGN.md section 3.4 has the measurements this structure follows from.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 #include "flyhip.h"
@@ -41,19 +42,26 @@ namespace {
 // stores and re-reads them: same CU, and nothing has read those lines since the kernel began).
 // Bit for bit what mlp_forward_sample followed by fly_step leave.
 constexpr int RS_LDS_FLOATS = FWD_LDS_FLOATS > ENVS_PER_BLOCK * FLY_NUM_OBS ? FWD_LDS_FLOATS : ENVS_PER_BLOCK * FLY_NUM_OBS;
+constexpr int RS_B3_LDS_FLOATS = FWD_B3_LDS_FLOATS > ENVS_PER_BLOCK * FLY_NUM_OBS ? FWD_B3_LDS_FLOATS : ENVS_PER_BLOCK * FLY_NUM_OBS;
 static_assert(ENVS_PER_BLOCK == BM && BLOCK == THREADS, "one forward tile = one env block");
 
-__global__ __launch_bounds__(THREADS, 2) void rollout_step_kernel(
-    const FlyConfig* __restrict__ c, FlyBuffers b, const float* __restrict__ P, const float* __restrict__ PF,
+// B3: the policy body on the bf16 matrix pipe (three-term splits; PF then points at the term planes)
+template <bool B3>
+__global__ __launch_bounds__(THREADS, B3 ? 1 : 2) void rollout_step_kernel(
+    const FlyConfig* __restrict__ c, FlyBuffers b, const float* __restrict__ P, const void* __restrict__ PF,
     const float* __restrict__ x, long n, const float* __restrict__ eps, const float* __restrict__ var, int var_steps,
     float var_decay, float var_min, float* __restrict__ act, float* __restrict__ logp, float* __restrict__ v_out)
 {
-    __shared__ __attribute__((aligned(16))) float lds[RS_LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[B3 ? RS_B3_LDS_FLOATS : RS_LDS_FLOATS];
     constexpr int PH_ALL = PH_SCALE | PH_RESET | PH_INTEGRATE | PH_OBS | PH_PROGRESS | PH_REWARD;
     FlyRegs st;
     fly_load<PH_ALL>(st, c, b, blockIdx.x);                 // the env state's HBM round trip hides under the forward
-    forward_body<false>(lds, blockIdx.x, 1L << 40, P, PF, x, n, nullptr, v_out, nullptr, nullptr, nullptr, nullptr, eps, var, act,
-                        logp, nullptr, var_steps, var_decay, var_min);
+    if (B3)
+        forward_body_b3<false>(lds, blockIdx.x, 1L << 40, P, static_cast<const u16*>(PF), x, n, nullptr, v_out, nullptr, nullptr,
+                               nullptr, nullptr, eps, var, act, logp, nullptr, var_steps, var_decay, var_min);
+    else
+        forward_body<false>(lds, blockIdx.x, 1L << 40, P, static_cast<const float*>(PF), x, n, nullptr, v_out, nullptr, nullptr,
+                            nullptr, nullptr, eps, var, act, logp, nullptr, var_steps, var_decay, var_min);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);          // this thread's action stores are acknowledged by L2
     __syncthreads();
@@ -204,10 +212,15 @@ extern "C" int flyhip_debug_mlp_fwd_bwd_stamped(const float* P, const float* PF,
 extern "C" hipError_t flyhip_launch_rollout_step(const FlyConfig* dcfg, const FlyBuffers* b, const float* P, const float* PF,
                                                  const float* x, int64_t n, const float* eps, const float* var, int var_steps,
                                                  float var_decay, float var_min, float* act, float* logp, float* v_out,
-                                                 void* stream)
+                                                 const uint16_t* PB, void* stream)
 {
-    hipLaunchKernelGGL(rollout_step_kernel, dim3((unsigned)((n + BM - 1) / BM)), dim3(THREADS), 0, (hipStream_t)stream, dcfg, *b,
-                       P, PF, x, (long)n, eps, var, var_steps, var_decay, var_min, act, logp, v_out);
+    const dim3 grid((unsigned)((n + BM - 1) / BM));
+    if (PB)
+        hipLaunchKernelGGL(rollout_step_kernel<true>, grid, dim3(THREADS), 0, (hipStream_t)stream, dcfg, *b, P, (const void*)PB,
+                           x, (long)n, eps, var, var_steps, var_decay, var_min, act, logp, v_out);
+    else
+        hipLaunchKernelGGL(rollout_step_kernel<false>, grid, dim3(THREADS), 0, (hipStream_t)stream, dcfg, *b, P, (const void*)PF,
+                           x, (long)n, eps, var, var_steps, var_decay, var_min, act, logp, v_out);
     return hipGetLastError();
 }
 

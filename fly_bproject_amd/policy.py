@@ -129,7 +129,7 @@ class PackedPolicy:
         # GEMM arithmetic of the MFMA kernels: "f32" = v_mfma_f32_32x32x2_f32, "bf16x3" = three-term bf16
         # split of both operands on v_mfma_f32_32x32x16_bf16 (fp32-accurate, see csrc/mlp_layout.h)
         self._gemm = os.environ.get("FLY_GEMM", "f32")
-        self.gemm_infer = os.environ.get("FLY_GEMM_INFER", "f32")
+        self.gemm_infer = os.environ.get("FLY_GEMM_INFER", self._gemm)
         assert self._gemm in ("f32", "bf16x3") and self.gemm_infer in ("f32", "bf16x3")
         self.PB = torch.zeros(PB_HALVES, dtype=torch.int16, device=self.device)
         self.PTB = torch.zeros(PTB_HALVES, dtype=torch.int16, device=self.device)
@@ -205,11 +205,13 @@ class PackedPolicy:
 
     @gemm.setter
     def gemm(self, mode):
-        """Switching to bf16x3 rebuilds the term planes: the Adam kernel only maintains them while a
-        bf16x3 mode is active (six extra scattered stores per weight otherwise wasted)."""
+        """Arithmetic of EVERY MLP GEMM of this policy: the update's forward, dX chain and dW, the rollout's
+        policy launch and the critic pass.  Switching to bf16x3 rebuilds the term planes: the Adam kernel only
+        maintains them while a bf16x3 mode is active (six extra scattered stores per weight otherwise wasted)."""
         assert mode in ("f32", "bf16x3")
         was_live = self._planes_live()
         self._gemm = mode
+        self.gemm_infer = mode
         if self._planes_live() and not was_live:
             self._refresh_planes()
     version = 0         # bumped whenever the weights change: consumers of cached network outputs compare it

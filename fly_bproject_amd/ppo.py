@@ -358,14 +358,15 @@ class PPO:
                         P(self._v_ring[t].data_ptr()), pol.infer_pb_ptr()))
             step.append((P(pol.P.data_ptr()), P(pol.PF.data_ptr()), P(self._obs_rows[t].data_ptr()),
                          P(self._eps_all[t].data_ptr()), var_ptr, self._var_steps, C.c_float(self._var_decay), self._var_min,
-                         P(self._act_rows[t].data_ptr()), P(self.all_log_prob[t].data_ptr()), P(self._v_ring[t].data_ptr())))
+                         P(self._act_rows[t].data_ptr()), P(self.all_log_prob[t].data_ptr()), P(self._v_ring[t].data_ptr()),
+                         pol.infer_pb_ptr()))
             book.append((P(self._reward_rows[t].data_ptr()), C.c_int64(n), P(self._score_acc.data_ptr()),
                          C.c_float(1.0 / self.num_eval_freq), var_ptr, C.c_int(self.num_acts)))
             bufs.append((self._obs_rows[t + 1].data_ptr(), self._reward_rows[t].data_ptr()))
         self._fwd_args, self._book_args, self._buf_ptrs, self._step_args = fwd, book, bufs, step
         # one launch per env step unless captured graphs or a bf16x3 inference body are asked for
-        self.fuse_rollout_step = (os.environ.get("FLY_FUSE_ROLLOUT_STEP", "1") != "0" and not self.use_graph
-                                  and pol.infer_pb_ptr() is None)
+        self.fuse_rollout_step = os.environ.get("FLY_FUSE_ROLLOUT_STEP", "1") != "0" and not self.use_graph
+        self._args_infer_gemm = pol.gemm_infer
 
     def _launch_step(self, t):
         """The device work of one env step (ppo.py:213-237): two launches, no host logic.  Rows of
@@ -405,8 +406,8 @@ class PPO:
         lean eager path on this stack: ~70 vs ~40 us per step; kept for experiments)."""
         t = self.mini_batch_number
         end = self.env.end
-        if self._fwd_args is None:
-            self._prepare_step_args()
+        if self._fwd_args is None or self._args_infer_gemm != self.policy.gemm_infer:
+            self._prepare_step_args()                               # (re)built when the inference arithmetic changes
         with torch.no_grad():
             if not self.use_graph or self.run_step < self.rollout_size:
                 self._launch_step(t)

@@ -241,11 +241,12 @@ int mlp_forward_sample(const float* params, const float* params_frag, const floa
  * (N = the handle's num_envs; fp32 MFMA arithmetic) writing act_out [N][18], logp_out [N] and the
  * optional v_out [N], then fly_step of the same envs with those actions (`b` as for fly_step: its
  * obs / reward rows are where the step's results go).  Workgroup k does both for envs 32k..32k+31,
- * so nothing waits on another workgroup.  Bit for bit what the two calls leave. */
+ * so nothing waits on another workgroup.  Bit for bit what the two calls leave.  params_b3 != NULL runs the
+ * policy on the bf16x3 GEMM arithmetic (as mlp_forward_sample with params_b3). */
 int ppo_rollout_step(FlyHandle h, const FlyBuffers* b, const float* params, const float* params_frag,
                      const float* x, const float* eps, const float* var, int32_t var_steps,
                      float var_decay, float var_min, float* act_out, float* logp_out, float* v_out,
-                     void* stream);
+                     const uint16_t* params_b3, void* stream);
 
 
 /*
