@@ -154,7 +154,7 @@ def kernel_rooflines(num_envs, T, reps):
     env.exit()
     t_gw = _time_launches(lambda: lib.mlp_grad_w(p(x), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(d["dz1"]), p(d["dz2"]),
                                                  p(d["dz3"]), p(d["dz4"]), rows, p(pol.workspace), p(pol.G), None, None, None,
-                                                 None, _lib.stream_ptr()), reps)
+                                                 None, 1 if pol.gemm == "bf16x3" else 0, _lib.stream_ptr()), reps)
     t_adam = _time_launches(lambda: pol.adam_step(), reps)
 
     def hbm(name, dur, bytes_per_launch, per_iter):

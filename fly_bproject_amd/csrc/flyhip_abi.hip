@@ -47,7 +47,7 @@ extern "C" int64_t flyhip_mlp_grad_workspace_floats(void);
 extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, const float* h2, const float* h3,
                                                const float* dz1, const float* dz2, const float* dz3, const float* dz4,
                                                int64_t n, float* workspace, float* grad_out, const float* norm_mask,
-                                               float* norm_ws, int* norm_step, const int* err, void* stream);
+                                               float* norm_ws, int* norm_step, const int* err, int gemm_b3, void* stream);
 extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PF, float* PT, const int* idx_f, const int* idx_t,
                                              const float* G, const float* mask, float* m,
                                              float* v, int* step, float lr, float beta1, float beta2, float eps,
@@ -354,7 +354,7 @@ int mlp_forward_backward(const float* params, const float* params_frag, const fl
 int mlp_grad_w(const float* x, const float* h1_saved, const float* h2_saved, const float* h3_saved,
                const float* dz1, const float* dz2, const float* dz3, const float* dz4, int64_t n,
                float* workspace, float* grad, const float* norm_mask, float* norm_ws, int32_t* norm_step,
-               const int32_t* err, void* stream)
+               const int32_t* err, int32_t gemm_b3, void* stream)
 {
     if ((norm_ws != nullptr) != (norm_mask != nullptr) || (norm_ws != nullptr) != (norm_step != nullptr))
         return fail(FLY_E_ARG, "mlp_grad_w: norm_mask, norm_ws and norm_step go together");
@@ -362,7 +362,7 @@ int mlp_grad_w(const float* x, const float* h1_saved, const float* h2_saved, con
         return fail(FLY_E_ARG, "mlp_grad_w: null pointer");
     if (n <= 0) return fail(FLY_E_ARG, "mlp_grad_w: n must be > 0");
     hipError_t e = flyhip_launch_mlp_grad_w(x, h1_saved, h2_saved, h3_saved, dz1, dz2, dz3, dz4, n, workspace, grad, norm_mask,
-                                            norm_ws, norm_step, err, stream);
+                                            norm_ws, norm_step, err, gemm_b3, stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_grad_w launch");
     return FLY_OK;
 }

@@ -153,6 +153,9 @@ extern "C" hipError_t flyhip_launch_mlp_backward_dx(const float* PT, const float
 // slabs are whole 32-row tiles; a chunk costs its MFMAs plus a fixed staging/barrier overhead, so the thin layers
 // (3 and 4) get more workgroups than their FLOP share: measured best of a dozen splits at 1280 tiles
 static int kGradWgs[4] = {80, 100, 52, 24};
+// the bf16x3 kernel (grad_w_b3.inc) pays a fixed staging + barrier cost per 16-row chunk, so its thin layers get
+// fewer rows each than their FLOP share: measured best of six splits at 1280 tiles (72 vs 82 us with the fp32 split)
+static int kGradWgsB3[4] = {72, 88, 64, 32};
 static bool gw_env_read = false;
 static void gw_read_env()
 {   // tuning aid: FLYHIP_GW_SPLIT="a,b,c,d" overrides the split (sum <= 256)
@@ -162,7 +165,7 @@ static void gw_read_env()
     int v[4];
     if (e && sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0 &&
         v[0] + v[1] + v[2] + v[3] <= 1024)
-        for (int i = 0; i < 4; ++i) kGradWgs[i] = v[i];
+        for (int i = 0; i < 4; ++i) kGradWgs[i] = kGradWgsB3[i] = v[i];
 }
 
 static int g_fb_consumer_shift = 0;     // test hook: moves the consumer range off its producers' XCDs (forces err = 2 in xcd mode)
@@ -227,14 +230,19 @@ extern "C" hipError_t flyhip_launch_rollout_step(const FlyConfig* dcfg, const Fl
 extern "C" int64_t flyhip_mlp_grad_workspace_floats(void)
 {
     gw_read_env();
-    return (int64_t)kGradWgs[0] * MLP_H1 * (MLP_IN_PAD + 1) + (int64_t)kGradWgs[1] * MLP_H2 * (MLP_H1 + 1) +
-           (int64_t)kGradWgs[2] * MLP_H3 * (MLP_H2 + 1) + (int64_t)kGradWgs[3] * MLP_OUT * (MLP_H3 + 1);   // N*KP + N per slab
+    int64_t need = 0;
+    for (const int* w : {kGradWgs, kGradWgsB3}) {
+        const int64_t f = (int64_t)w[0] * MLP_H1 * (MLP_IN_PAD + 1) + (int64_t)w[1] * MLP_H2 * (MLP_H1 + 1) +
+                          (int64_t)w[2] * MLP_H3 * (MLP_H2 + 1) + (int64_t)w[3] * MLP_OUT * (MLP_H3 + 1);   // N*KP + N per slab
+        need = f > need ? f : need;
+    }
+    return need;
 }
 
 extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, const float* h2, const float* h3,
                                                const float* dz1, const float* dz2, const float* dz3, const float* dz4,
                                                int64_t n, float* workspace, float* grad_out, const float* norm_mask,
-                                               float* norm_ws, int* norm_step, const int* err, void* stream)
+                                               float* norm_ws, int* norm_step, const int* err, int gemm_b3, void* stream)
 {
     gw_read_env();
     GradWTable T;
@@ -245,11 +253,12 @@ extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, 
     const int KP[4] = {MLP_IN_PAD, MLP_H1, MLP_H2, MLP_H3};
     float* ws = workspace;
     int first = 0;
+    const int* wgs = gemm_b3 ? kGradWgsB3 : kGradWgs;
     for (int l = 0; l < 4; ++l) {
         T.l[l].dz = dz[l]; T.l[l].a = a[l]; T.l[l].partial = ws;
-        T.l[l].N = N[l]; T.l[l].Ka = Ka[l]; T.l[l].KP = KP[l]; T.l[l].wgs = kGradWgs[l]; T.l[l].first_block = first;
-        ws += (long)kGradWgs[l] * ((long)N[l] * KP[l] + N[l]);
-        first += kGradWgs[l];
+        T.l[l].N = N[l]; T.l[l].Ka = Ka[l]; T.l[l].KP = KP[l]; T.l[l].wgs = wgs[l]; T.l[l].first_block = first;
+        ws += (long)wgs[l] * ((long)N[l] * KP[l] + N[l]);
+        first += wgs[l];
     }
     // dynamic LDS: two buffers of the largest layer's chunk (padded pitches): 2 x 32 x (136 + 264) floats = 100 KiB
     const size_t lds_bytes = sizeof(float) * 2 * GW_ROWS * (MLP_H2 + GW_PAD + MLP_H1 + GW_PAD);
@@ -261,7 +270,20 @@ extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, 
         if (ea != hipSuccess) return ea;
         attr_set = true;
     }
-    hipLaunchKernelGGL(mlp_grad_w_kernel, dim3(first), dim3(GW_THREADS), lds_bytes, (hipStream_t)stream, T, (long)n);
+    if (gemm_b3) {
+        // two buffers of three bf16 term planes of a 16-row chunk: 2 x 3 x 16 x (288 + 160) x 2 B = 84 KiB
+        const size_t b3_bytes = 2 * 3 * GB_ROWS * (gb_pitch<MLP_H1>() + gb_pitch<MLP_H2>()) * sizeof(u16);
+        static bool b3_attr_set = false;
+        if (!b3_attr_set) {
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_grad_w_b3_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)b3_bytes);
+            if (ea != hipSuccess) return ea;
+            b3_attr_set = true;
+        }
+        hipLaunchKernelGGL(mlp_grad_w_b3_kernel, dim3(first), dim3(GW_THREADS), b3_bytes, (hipStream_t)stream, T, (long)n);
+    } else {
+        hipLaunchKernelGGL(mlp_grad_w_kernel, dim3(first), dim3(GW_THREADS), lds_bytes, (hipStream_t)stream, T, (long)n);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3(RED_BLOCKS), dim3(64 * RED_WAVES), 0,

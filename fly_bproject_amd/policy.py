@@ -339,7 +339,7 @@ class PackedPolicy:
         nm = (p(self.grad_mask), p(self._norm_ws), p(self.step)) if fuse_norm else (None, None, None)
         _lib.check(self._lib.mlp_grad_w(p(x), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(d["dz1"]), p(d["dz2"]),
                                         p(d["dz3"]), p(d["dz4"]), C.c_int64(n), p(self.workspace), p(self.G), *nm,
-                                        p(self.tile_wait_error), st),
+                                        p(self.tile_wait_error), C.c_int(1 if self.gemm == "bf16x3" else 0), st),
                    "mlp_grad_w")
 
     def loss_value(self, n):

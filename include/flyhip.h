@@ -262,6 +262,8 @@ int ppo_rollout_step(FlyHandle h, const FlyBuffers* b, const float* params, cons
  *                     non-NULL (single rank: nothing sits between this call and the optimizer)
  *                     the reduction also leaves the clip-norm partial sums in norm_ws (>= 1280
  *                     floats) and advances *norm_step; pass norm_ready = 1 to mlp_adam_step then.
+ *                     gemm_b3 != 0 runs the products on the bf16 matrix pipe with both operands
+ *                     split into three bf16 terms at staging (the bf16x3 arithmetic of mlp_forward).
  *                     `err` (optional) = the err word of mlp_forward_backward: while it is nonzero
  *                     grad[76] (padding column 76 of W1 row 0: masked, never a parameter) is set
  *                     to 1 instead of 0 and *norm_step is not advanced.  The flag rides inside the
@@ -314,7 +316,7 @@ int mlp_forward_backward(const float* params, const float* params_frag, const fl
 int mlp_grad_w(const float* x, const float* h1_saved, const float* h2_saved, const float* h3_saved,
                const float* dz1, const float* dz2, const float* dz3, const float* dz4, int64_t n,
                float* workspace, float* grad, const float* norm_mask, float* norm_ws, int32_t* norm_step,
-               const int32_t* err, void* stream);
+               const int32_t* err, int32_t gemm_b3, void* stream);
 int mlp_adam_step(float* params, float* params_frag, float* params_t_frag, const int32_t* idx_frag,
                   const int32_t* idx_t_frag, const float* grad, const float* mask, float* exp_avg,
                   float* exp_avg_sq, int32_t* step, float lr, float beta1, float beta2, float eps,

@@ -21,7 +21,7 @@ for t in list(pol.saves.values()) + list(pol.dz.values()):
 p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
 s, d = pol.saves, pol.dz
 fn = lambda: lib.mlp_grad_w(p(x), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(d["dz1"]), p(d["dz2"]), p(d["dz3"]), p(d["dz4"]), rows,   # noqa: E731
-                            p(pol.workspace), p(pol.G), None, None, None, None, None)
+                            p(pol.workspace), p(pol.G), None, None, None, None, int(os.environ.get('B3', '0')), None)
 for _ in range(5):
     fn()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
