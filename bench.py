@@ -146,11 +146,11 @@ def kernel_rooflines(num_envs, T, reps):
     a_o = torch.empty(num_envs, 18, device="cuda:0"); lp_o = torch.empty(num_envs, device="cuda:0")
     v_o = torch.empty(num_envs, device="cuda:0")
     t_pol = _time_launches(lambda: lib.mlp_forward_sample(p(pol.P), p(pol.PF), p(xs), num_envs, p(eps), p(var), 0, 0.0, 0.0, p(a_o),
-                                                          p(lp_o), None, p(v_o), pol.infer_pb_ptr(), _lib.stream_ptr()), reps)
+                                                          p(lp_o), None, p(v_o), pol.infer_pb_ptr(), None, _lib.stream_ptr()), reps)
     # the loop's env step: policy + sampling + env step of every 32-env tile in ONE launch
     t_roll = _time_launches(lambda: lib.ppo_rollout_step(env._handle, C.byref(env._bufs), p(pol.P), p(pol.PF), p(xs), p(eps),
                                                          p(var), 0, 0.0, 0.0, p(a_o), p(lp_o), p(v_o), pol.infer_pb_ptr(),
-                                                         _lib.stream_ptr()), reps)
+                                                         None, _lib.stream_ptr()), reps)
     env.exit()
     t_gw = _time_launches(lambda: lib.mlp_grad_w(p(x), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(d["dz1"]), p(d["dz2"]),
                                                  p(d["dz3"]), p(d["dz4"]), rows, p(pol.workspace), p(pol.G), None, None, None,

@@ -36,10 +36,10 @@ SYMBOLS = {
     "ppo_adv_stats": [_P, _L, _P, _P],
     "ppo_adv_apply": [_P, _L, _P, _F, _F, _P],
     "ppo_step_bookkeeping": [_P, _L, _P, _F, _P, _I, _F, _F, _P],
-    "ppo_rollout_step": [_P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _P],
-    "ppo_rollout_bookkeeping": [_P, _L, _L, _P, _P, _F, _P, _I, _F, _F, _P],
+    "ppo_rollout_step": [_P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _P, _P],
+    "ppo_rollout_bookkeeping": [_P, _L, _L, _P, _P, _F, _P, _I, _F, _F, _P, _P],
     "mlp_forward": [_P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P],
-    "mlp_forward_sample": [_P, _P, _P, _L, _P, _P, _I, _F, _F, _P, _P, _P, _P, _P],
+    "mlp_forward_sample": [_P, _P, _P, _L, _P, _P, _I, _F, _F, _P, _P, _P, _P, _P, _P],
     "mlp_grad_workspace_floats": [],
     "mlp_backward_dx": [_P] * 10 + [_L, _F, _F, _P, _P, _P, _P, _P, _P, _P],
     "mlp_forward_backward": [_P] * 4 + [_L] + [_P] * 9 + [_F, _F] + [_P] * 6 + [_I, _P, _P, _P, _I, _P],

@@ -69,7 +69,7 @@ extern "C" hipError_t flyhip_launch_mlp_forward_sample(const float* P, const flo
                                                        const float* eps, const float* var, int var_steps,
                                                        float var_decay, float var_min, float* act_out,
                                                        float* logp_out, float* mu_out, float* v_out, const uint16_t* PB,
-                                                       void* stream);
+                                                       const int* var_base, void* stream);
 
 extern "C" hipError_t flyhip_launch_mlp_fwd_bwd(const float* P, const float* PF, const float* PT, const float* x, int64_t n,
                                                 float* out_save, float* h1_save, float* h2_save, float* h3_save,
@@ -80,11 +80,11 @@ extern "C" hipError_t flyhip_launch_mlp_fwd_bwd(const float* P, const float* PF,
                                                 int coherent, void* stream);
 extern "C" hipError_t flyhip_launch_rollout_bookkeeping(const float* reward, int64_t rows, int64_t n, float* terms,
                                                         float* score_acc, float score_scale, float* action_var, int nvar,
-                                                        float var_decay, float var_min, void* stream);
+                                                        float var_decay, float var_min, int* rows_applied, void* stream);
 extern "C" hipError_t flyhip_launch_rollout_step(const FlyConfig* dcfg, const FlyBuffers* b, const float* P, const float* PF,
                                                  const float* x, int64_t n, const float* eps, const float* var, int var_steps,
                                                  float var_decay, float var_min, float* act, float* logp, float* v_out,
-                                                 const uint16_t* PB, void* stream);
+                                                 const uint16_t* PB, const int* var_base, void* stream);
 extern "C" hipError_t flyhip_launch_adv_stats(const float* adv, int64_t n, float* stats, void* stream);
 extern "C" hipError_t flyhip_launch_adv_apply(float* adv, int64_t n, const float* totals, float count, float eps, void* stream);
 
@@ -191,7 +191,8 @@ int fly_step(FlyHandle h, const float* actions, const FlyBuffers* b, void* strea
 
 int ppo_rollout_step(FlyHandle h, const FlyBuffers* b, const float* params, const float* params_frag, const float* x,
                      const float* eps, const float* var, int32_t var_steps, float var_decay, float var_min,
-                     float* act_out, float* logp_out, float* v_out, const uint16_t* params_b3, void* stream)
+                     float* act_out, float* logp_out, float* v_out, const uint16_t* params_b3,
+                     const int32_t* var_steps_base, void* stream)
 {
     if (!h) return fail(FLY_E_ARG, "handle is null");
     if (!params || !params_frag || !x || !eps || !var || !act_out || !logp_out)
@@ -200,7 +201,7 @@ int ppo_rollout_step(FlyHandle h, const FlyBuffers* b, const float* params, cons
     int rc = check_buffers(b, PH_SCALE | PH_RESET | PH_INTEGRATE | PH_OBS | PH_PROGRESS | PH_REWARD);
     if (rc) return rc;
     hipError_t e = flyhip_launch_rollout_step(h->dev, b, params, params_frag, x, h->host.num_envs, eps, var, var_steps,
-                                              var_decay, var_min, act_out, logp_out, v_out, params_b3, stream);
+                                              var_decay, var_min, act_out, logp_out, v_out, params_b3, var_steps_base, stream);
     if (e != hipSuccess) return hip_fail(e, "ppo_rollout_step launch");
     return FLY_OK;
 }
@@ -261,13 +262,13 @@ int ppo_adv_apply(float* adv, int64_t n, const float* totals, float count, float
 
 int ppo_rollout_bookkeeping(const float* reward, int64_t rows, int64_t n, float* terms, float* score_acc,
                             float score_scale, float* action_var, int32_t nvar, float var_decay,
-                            float var_min, void* stream)
+                            float var_min, int32_t* rows_applied, void* stream)
 {
     if (!reward || !terms || !score_acc || !action_var) return fail(FLY_E_ARG, "ppo_rollout_bookkeeping: null pointer");
     if (rows < 0 || n <= 0 || nvar < 0 || nvar > 63) return fail(FLY_E_ARG, "ppo_rollout_bookkeeping: bad size");
     if (rows == 0) return FLY_OK;
     hipError_t e = flyhip_launch_rollout_bookkeeping(reward, rows, n, terms, score_acc, score_scale, action_var, nvar,
-                                                     var_decay, var_min, stream);
+                                                     var_decay, var_min, rows_applied, stream);
     if (e != hipSuccess) return hip_fail(e, "ppo_rollout_bookkeeping launch");
     return FLY_OK;
 }
@@ -298,14 +299,14 @@ int mlp_forward(const float* params, const float* params_frag, const float* x, i
 int mlp_forward_sample(const float* params, const float* params_frag, const float* x, int64_t n,
                        const float* eps, const float* var, int32_t var_steps, float var_decay,
                        float var_min, float* act_out, float* logp_out, float* mu_out, float* v_out,
-                       const uint16_t* params_b3, void* stream)
+                       const uint16_t* params_b3, const int32_t* var_steps_base, void* stream)
 {
     if (!params || !params_frag || !x || !eps || !var || !act_out || !logp_out)
         return fail(FLY_E_ARG, "mlp_forward_sample: null pointer");
     if (n <= 0) return fail(FLY_E_ARG, "mlp_forward_sample: n must be > 0");
     if (var_steps < 0 || var_steps > (1 << 20)) return fail(FLY_E_ARG, "mlp_forward_sample: var_steps out of range");
     hipError_t e = flyhip_launch_mlp_forward_sample(params, params_frag, x, n, eps, var, var_steps, var_decay, var_min, act_out, logp_out,
-                                                    mu_out, v_out, params_b3, stream);
+                                                    mu_out, v_out, params_b3, var_steps_base, stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_forward_sample launch");
     return FLY_OK;
 }

@@ -50,9 +50,11 @@ template <bool B3>
 __global__ __launch_bounds__(THREADS, B3 ? 1 : 2) void rollout_step_kernel(
     const FlyConfig* __restrict__ c, FlyBuffers b, const float* __restrict__ P, const void* __restrict__ PF,
     const float* __restrict__ x, long n, const float* __restrict__ eps, const float* __restrict__ var, int var_steps,
-    float var_decay, float var_min, float* __restrict__ act, float* __restrict__ logp, float* __restrict__ v_out)
+    float var_decay, float var_min, float* __restrict__ act, float* __restrict__ logp, float* __restrict__ v_out,
+    const int* __restrict__ var_base)
 {
     __shared__ __attribute__((aligned(16))) float lds[B3 ? RS_B3_LDS_FLOATS : RS_LDS_FLOATS];
+    var_steps -= var_base ? *var_base : 0;                  // pending decays: frozen row index minus what is already applied
     constexpr int PH_ALL = PH_SCALE | PH_RESET | PH_INTEGRATE | PH_OBS | PH_PROGRESS | PH_REWARD;
     FlyRegs st;
     fly_load<PH_ALL>(st, c, b, blockIdx.x);                 // the env state's HBM round trip hides under the forward
@@ -79,7 +81,7 @@ extern "C" hipError_t flyhip_launch_mlp_forward(const float* P, const float* PF,
         const int grid = (int)tiles;
         hipLaunchKernelGGL(mlp_forward_b3_kernel, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PB, x, (long)n, mu_out,
                            v_out, out_save, h1_save, h2_save, h3_save, (const float*)nullptr, (const float*)nullptr,
-                           (float*)nullptr, (float*)nullptr, 0, 0.0f, 0.0f);
+                           (float*)nullptr, (float*)nullptr, 0, 0.0f, 0.0f, (const int*)nullptr);
         return hipGetLastError();
     }
     // Large inputs (the critic pass over the whole rollout) run persistent workgroups, 3 per CU, each
@@ -90,7 +92,7 @@ extern "C" hipError_t flyhip_launch_mlp_forward(const float* P, const float* PF,
     const int grid = (int)(tiles <= 4 * PERSIST_GRID ? tiles : PERSIST_GRID);
     hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PF, x, (long)n,
                        mu_out, v_out, out_save, h1_save, h2_save, h3_save, (const float*)nullptr, (const float*)nullptr,
-                       (float*)nullptr, (float*)nullptr, (unsigned long long*)nullptr, 0, 0.0f, 0.0f);
+                       (float*)nullptr, (float*)nullptr, (unsigned long long*)nullptr, 0, 0.0f, 0.0f, (const int*)nullptr);
     return hipGetLastError();
 }
 
@@ -98,21 +100,21 @@ extern "C" hipError_t flyhip_launch_mlp_forward_sample(const float* P, const flo
                                                        const float* eps, const float* var, int var_steps,
                                                        float var_decay, float var_min, float* act_out,
                                                        float* logp_out, float* mu_out, float* v_out, const uint16_t* PB,
-                                                       void* stream)
+                                                       const int* var_base, void* stream)
 {
     if (PB) {
         const long tiles = (n + BM - 1) / BM;
         const int grid = (int)tiles;
         hipLaunchKernelGGL(mlp_forward_b3_kernel, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PB, x, (long)n, mu_out,
                            v_out, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, eps, var, act_out,
-                           logp_out, var_steps, var_decay, var_min);
+                           logp_out, var_steps, var_decay, var_min, var_base);
         return hipGetLastError();
     }
     const long tiles = (n + BM - 1) / BM;
     const int grid = (int)(tiles <= 4 * PERSIST_GRID ? tiles : PERSIST_GRID);
     hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PF, x, (long)n,
                        mu_out, v_out, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, eps,
-                       var, act_out, logp_out, (unsigned long long*)nullptr, var_steps, var_decay, var_min);
+                       var, act_out, logp_out, (unsigned long long*)nullptr, var_steps, var_decay, var_min, var_base);
     return hipGetLastError();
 }
 
@@ -125,7 +127,7 @@ extern "C" int flyhip_debug_mlp_forward_stamped(const float* P, const float* PF,
     const int grid = grid_override > 0 ? grid_override : (int)(tiles <= 4 * PERSIST_GRID ? tiles : PERSIST_GRID);
     hipLaunchKernelGGL(mlp_forward_kernel<true>, dim3(grid), dim3(THREADS), 0, (hipStream_t)stream, P, PF, x, (long)n,
                        (float*)nullptr, (float*)nullptr, out_save, h1_save, h2_save, h3_save, (const float*)nullptr,
-                       (const float*)nullptr, (float*)nullptr, (float*)nullptr, stamps, 0, 0.0f, 0.0f);
+                       (const float*)nullptr, (float*)nullptr, (float*)nullptr, stamps, 0, 0.0f, 0.0f, (const int*)nullptr);
     return (int)hipGetLastError();
 }
 
@@ -215,15 +217,15 @@ extern "C" int flyhip_debug_mlp_fwd_bwd_stamped(const float* P, const float* PF,
 extern "C" hipError_t flyhip_launch_rollout_step(const FlyConfig* dcfg, const FlyBuffers* b, const float* P, const float* PF,
                                                  const float* x, int64_t n, const float* eps, const float* var, int var_steps,
                                                  float var_decay, float var_min, float* act, float* logp, float* v_out,
-                                                 const uint16_t* PB, void* stream)
+                                                 const uint16_t* PB, const int* var_base, void* stream)
 {
     const dim3 grid((unsigned)((n + BM - 1) / BM));
     if (PB)
         hipLaunchKernelGGL(rollout_step_kernel<true>, grid, dim3(THREADS), 0, (hipStream_t)stream, dcfg, *b, P, (const void*)PB,
-                           x, (long)n, eps, var, var_steps, var_decay, var_min, act, logp, v_out);
+                           x, (long)n, eps, var, var_steps, var_decay, var_min, act, logp, v_out, var_base);
     else
         hipLaunchKernelGGL(rollout_step_kernel<false>, grid, dim3(THREADS), 0, (hipStream_t)stream, dcfg, *b, P, (const void*)PF,
-                           x, (long)n, eps, var, var_steps, var_decay, var_min, act, logp, v_out);
+                           x, (long)n, eps, var, var_steps, var_decay, var_min, act, logp, v_out, var_base);
     return hipGetLastError();
 }
 

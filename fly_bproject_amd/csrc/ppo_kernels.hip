@@ -257,13 +257,14 @@ __global__ __launch_bounds__(1024) void ppo_row_terms_kernel(const float* __rest
 
 __global__ __launch_bounds__(64) void ppo_rows_apply_kernel(const float* __restrict__ terms, long rows,
                                                             float* __restrict__ score_acc, float* __restrict__ action_var,
-                                                            int nvar, float var_decay, float var_min)
+                                                            int nvar, float var_decay, float var_min, int* __restrict__ rows_applied)
 {
     const int tid = threadIdx.x;
     if (tid == 63) {
         float acc = *score_acc;
         for (long r = 0; r < rows; ++r) acc += terms[r];
         *score_acc = acc;
+        if (rows_applied) *rows_applied += (int)rows;       // the policy launches subtract this from their row index
     }
     if (tid < nvar && var_decay > 0.0f) {
         float v = action_var[tid];
@@ -276,12 +277,12 @@ __global__ __launch_bounds__(64) void ppo_rows_apply_kernel(const float* __restr
 
 extern "C" hipError_t flyhip_launch_rollout_bookkeeping(const float* reward, int64_t rows, int64_t n, float* terms,
                                                         float* score_acc, float score_scale, float* action_var, int nvar,
-                                                        float var_decay, float var_min, void* stream)
+                                                        float var_decay, float var_min, int* rows_applied, void* stream)
 {
     hipLaunchKernelGGL(ppo_row_terms_kernel, dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream, reward, (long)n,
                        score_scale, terms);
     hipLaunchKernelGGL(ppo_rows_apply_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, terms, (long)rows, score_acc,
-                       action_var, nvar, var_decay, var_min);
+                       action_var, nvar, var_decay, var_min, rows_applied);
     return hipGetLastError();
 }
 

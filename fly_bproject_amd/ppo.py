@@ -199,7 +199,8 @@ class PPO:
         _lib.check(self._lib.ppo_rollout_bookkeeping(
             P(self.all_reward[self._book_from].data_ptr()), C.c_int64(rows), C.c_int64(n), P(self._book_terms.data_ptr()),
             P(self._score_acc.data_ptr()), C.c_float(1.0 / self.num_eval_freq), P(self._action_var.data_ptr()),
-            C.c_int(self.num_acts), C.c_float(self._var_decay), self._var_min, _lib.stream_ptr()), "ppo_rollout_bookkeeping")
+            C.c_int(self.num_acts), C.c_float(self._var_decay), self._var_min, P(self._rows_applied.data_ptr()),
+            _lib.stream_ptr()), "ppo_rollout_bookkeeping")
         self._book_from = self._rows_done
 
     def make_data(self):
@@ -344,28 +345,32 @@ class PPO:
         self._obs_rows = [self._obs_ring[t] for t in range(T + 1)]
         self._reward_rows = [self.all_reward[t].view(-1) for t in range(T)]
         self._act_rows = [self.all_acts[t] for t in range(T)]
-        fwd, book, bufs, step = [], [], [], []
+        fwd, bufs, step = [], [], []
         self._var_decay = 0.0 if self.args.testing else 0.00001     # ppo.py:236
         self._var_min = C.c_float(0.01)
-        self._var_steps = C.c_int(0)                                 # pending decays, set before every policy launch
         self._book_terms = torch.zeros(T, device=self.device)       # scratch of ppo_rollout_bookkeeping
-        self._lazy_book = not self.use_graph                         # captured launches freeze their arguments
+        # The policy launch of row t derives its variance from the tensor and the decays still pending:
+        # t - (rows of this rollout already applied).  The second term lives in a DEVICE word that
+        # ppo_rollout_bookkeeping advances, so the launch arguments of row t never change -- the same tuple
+        # serves every rollout, eager or replayed from a captured hipGraph.
+        self._rows_applied = torch.zeros(1, dtype=torch.int32, device=self.device)
+        base_ptr = P(self._rows_applied.data_ptr())
         var_ptr = P(self._action_var.data_ptr())
         for t in range(T):
             fwd.append((P(pol.P.data_ptr()), P(pol.PF.data_ptr()), P(self._obs_rows[t].data_ptr()), C.c_int64(n),
-                        P(self._eps_all[t].data_ptr()), var_ptr, self._var_steps, C.c_float(self._var_decay), self._var_min,
+                        P(self._eps_all[t].data_ptr()), var_ptr, C.c_int(t), C.c_float(self._var_decay), self._var_min,
                         P(self._act_rows[t].data_ptr()), P(self.all_log_prob[t].data_ptr()), None,
-                        P(self._v_ring[t].data_ptr()), pol.infer_pb_ptr()))
+                        P(self._v_ring[t].data_ptr()), pol.infer_pb_ptr(), base_ptr))
             step.append((P(pol.P.data_ptr()), P(pol.PF.data_ptr()), P(self._obs_rows[t].data_ptr()),
-                         P(self._eps_all[t].data_ptr()), var_ptr, self._var_steps, C.c_float(self._var_decay), self._var_min,
+                         P(self._eps_all[t].data_ptr()), var_ptr, C.c_int(t), C.c_float(self._var_decay), self._var_min,
                          P(self._act_rows[t].data_ptr()), P(self.all_log_prob[t].data_ptr()), P(self._v_ring[t].data_ptr()),
-                         pol.infer_pb_ptr()))
-            book.append((P(self._reward_rows[t].data_ptr()), C.c_int64(n), P(self._score_acc.data_ptr()),
-                         C.c_float(1.0 / self.num_eval_freq), var_ptr, C.c_int(self.num_acts)))
+                         pol.infer_pb_ptr(), base_ptr))
             bufs.append((self._obs_rows[t + 1].data_ptr(), self._reward_rows[t].data_ptr()))
-        self._fwd_args, self._book_args, self._buf_ptrs, self._step_args = fwd, book, bufs, step
+        self._fwd_args, self._buf_ptrs, self._step_args = fwd, bufs, step
+        self._graphs = {}                                            # captured steps hold the old pointers
         # one launch per env step unless captured graphs or a bf16x3 inference body are asked for
-        self.fuse_rollout_step = os.environ.get("FLY_FUSE_ROLLOUT_STEP", "1") != "0" and not self.use_graph
+        # one launch per env step, eager or captured
+        self.fuse_rollout_step = os.environ.get("FLY_FUSE_ROLLOUT_STEP", "1") != "0"
         self._args_infer_gemm = pol.gemm_infer
 
     def _launch_step(self, t):
@@ -376,9 +381,7 @@ class PPO:
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         if t == 0:
             self._eps_all.normal_(generator=self._gen)              # the eps of MultivariateNormal.sample, whole rollout
-        if t == 0:
-            self._rows_done = self._book_from = 0
-        self._var_steps.value = (t - self._book_from) if self._lazy_book else 0
+            self._rows_applied.zero_()                              # a new rollout: no row's bookkeeping applied yet
         env.obs_buf, env.reward_buf = self._obs_rows[t + 1], self._reward_rows[t]      # ppo.py:228-229
         env._bufs.obs, env._bufs.reward = self._buf_ptrs[t]
         if self.fuse_rollout_step:
@@ -387,23 +390,26 @@ class PPO:
         else:
             rc = lib.mlp_forward_sample(*self._fwd_args[t], st)     # ppo.py:214-220, :227 (policy + sampling fused)
             rc |= lib.fly_step(env._handle, C.c_void_p(self._act_rows[t].data_ptr()), C.byref(env._bufs), st)  # ppo.py:223
+        if rc:
+            _lib.check(rc, "rollout step")
+        self._after_step(t)
+        env.render_count += 1
+
+    def _after_step(self, t):
+        """Host-side state of a step that has been issued (launched or replayed): rows whose score / variance
+        bookkeeping is pending (ppo.py:233, :236-237, applied by _flush_bookkeeping) and how many rows of
+        v(obs_t) the rollout's policy launches have left for make_data."""
         if t == 0:
+            self._book_from = 0
             self._v_have, self._v_version = 1, self.policy.version
         elif self._v_have == t:
             self._v_have = t + 1
-        # ppo.py:230 (all_done): see the property.  ppo.py:233 + :236-237: deferred, or one tiny launch
-        if self._lazy_book:
-            self._rows_done = t + 1
-        else:
-            rc |= lib.ppo_step_bookkeeping(*self._book_args[t], C.c_float(self._var_decay), self._var_min, st)
-        if rc:
-            _lib.check(rc, "rollout step")
-        env.render_count += 1
+        self._rows_done = t + 1
 
     def run(self):
         """ppo.py:204-264: one env step of the rollout (and an update when the rollout is full).
-        `graph=True` replays the step from a captured hipGraph instead (measured slower than the
-        lean eager path on this stack: ~70 vs ~40 us per step; kept for experiments)."""
+        `graph=True` replays the device work of a whole rollout from ONE captured hipGraph (the first
+        rollout runs eagerly, the second captures)."""
         t = self.mini_batch_number
         end = self.env.end
         if self._fwd_args is None or self._args_infer_gemm != self.policy.gemm_infer:
@@ -412,18 +418,29 @@ class PPO:
             if not self.use_graph or self.run_step < self.rollout_size:
                 self._launch_step(t)
             else:
-                key = (t, bool(self.args.testing))
-                g = self._graphs.get(key)
-                if g is None:
-                    g = torch.cuda.CUDAGraph()
-                    g.register_generator_state(self._gen)
-                    torch.cuda.synchronize(self.device)
-                    with torch.cuda.graph(g):
-                        self._launch_step(t)
-                    self._graphs[key] = g
+                # graph=True: the device work of a WHOLE rollout (eps draw + T one-launch env steps) is one
+                # captured hipGraph, replayed when the rollout's first step is asked for; the later run() calls of
+                # the rollout only advance the host-side counters.  (A graph per step cannot win: the step is
+                # GPU-bound and every replay pays a graph launch of its own -- tools/graph_vs_eager.py.)  The
+                # deferred bookkeeping makes this exact: row t's launch carries the frozen row index, the
+                # device word `_rows_applied` is zeroed inside the graph, and a flush only ever covers the rows
+                # the HOST has counted as done.
+                if t == 0:
+                    key = bool(self.args.testing)
+                    g = self._graphs.get(key)
+                    if g is None:
+                        g = torch.cuda.CUDAGraph()
+                        g.register_generator_state(self._gen)
+                        torch.cuda.synchronize(self.device)
+                        with torch.cuda.graph(g):
+                            for tt in range(self.rollout_size):
+                                self._launch_step(tt)
+                        self._graphs[key] = g
+                    g.replay()
                 self.env.obs_buf, self.env.reward_buf = self._obs_rows[t + 1], self._reward_rows[t]
                 self.env._bufs.obs, self.env._bufs.reward = self._buf_ptrs[t]
-                g.replay()
+                self._after_step(t)
+                self.env.render_count += 1
 
         if t + 1 == self.rollout_size:                              # ppo.py:240-252
             self._flush_bookkeeping()                               # the update reads the decayed variance

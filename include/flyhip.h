@@ -192,10 +192,11 @@ int ppo_step_bookkeeping(const float* reward, int64_t n, float* score_acc, float
  * `rows` calls of ppo_step_bookkeeping on the rows of reward f32 [rows][n] leave (score terms are
  * added in row order, the variance is decayed `rows` times).  `terms` is a device scratch of
  * >= rows floats.  The rollout calls it when the score is printed and before an update instead of
- * launching the per-step form on every env step. */
+ * launching the per-step form on every env step.  rows_applied (optional device int32) += rows: the
+ * word mlp_forward_sample / ppo_rollout_step subtract from their row index (var_steps_base). */
 int ppo_rollout_bookkeeping(const float* reward, int64_t rows, int64_t n, float* terms, float* score_acc,
                             float score_scale, float* action_var, int32_t nvar, float var_decay,
-                            float var_min, void* stream);
+                            float var_min, int32_t* rows_applied, void* stream);
 
 /*
  * Actor-critic MLP on the matrix cores (fp32-in/fp32-accumulate MFMA), reference ppo.py:10-102
@@ -231,11 +232,14 @@ int mlp_forward(const float* params, const float* params_frag, const float* x, i
  * would recompute with unchanged weights) are optional.  The variance used is `var` after
  * `var_steps` applications of v <- max(var_min, v - var_decay) (ppo.py:236-237), computed in the
  * kernel without touching `var`: the caller may apply the decays of a whole rollout to the tensor
- * later (ppo_rollout_bookkeeping).  var_steps = 0 uses `var` as is. */
+ * later (ppo_rollout_bookkeeping).  var_steps = 0 uses `var` as is.  var_steps_base (optional device int32):
+ * the pending decays are var_steps - *var_steps_base -- pass the rollout's row index as var_steps and the
+ * word ppo_rollout_bookkeeping advances: the launch arguments then never change for a given row, so the
+ * launch can be replayed from a captured hipGraph while the bookkeeping stays deferred. */
 int mlp_forward_sample(const float* params, const float* params_frag, const float* x, int64_t n,
                        const float* eps, const float* var, int32_t var_steps, float var_decay,
                        float var_min, float* act_out, float* logp_out, float* mu_out, float* v_out,
-                       const uint16_t* params_b3, void* stream);
+                       const uint16_t* params_b3, const int32_t* var_steps_base, void* stream);
 
 /* One env step of the rollout (ppo.py:213-230) in ONE launch: mlp_forward_sample on x f32 [N][73]
  * (N = the handle's num_envs; fp32 MFMA arithmetic) writing act_out [N][18], logp_out [N] and the
@@ -246,7 +250,7 @@ int mlp_forward_sample(const float* params, const float* params_frag, const floa
 int ppo_rollout_step(FlyHandle h, const FlyBuffers* b, const float* params, const float* params_frag,
                      const float* x, const float* eps, const float* var, int32_t var_steps,
                      float var_decay, float var_min, float* act_out, float* logp_out, float* v_out,
-                     const uint16_t* params_b3, void* stream);
+                     const uint16_t* params_b3, const int32_t* var_steps_base, void* stream);
 
 
 /*

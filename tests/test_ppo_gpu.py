@@ -137,24 +137,36 @@ def test_rollout_values_equal_the_critic_pass():
 
 
 def test_graph_replay_matches_eager_rollout():
-    """Rollout steps replayed from captured hipGraphs leave exactly what the eager launches leave
-    (same seeds; the captured normal_ advances the Philox offset like the eager call)."""
+    """graph=True replays the device work of a whole rollout from ONE captured hipGraph (the captured normal_
+    advances the Philox offset like the eager call).  After whole rollouts everything equals the eager run bit for
+    bit -- also when the score print's mid-rollout bookkeeping flush falls inside a replayed rollout (run_step 200,
+    300 below).  Mid-rollout the DEVICE is ahead of the host's step count (documented in PPO.run): the rows the
+    host has stepped through are final, env.reset_buf / progress_buf already hold the rollout's end state."""
     from fly_bproject_amd.ppo import PPO
     res = {}
     for graph in (False, True):
         torch.manual_seed(0)
         with contextlib.redirect_stdout(io.StringIO()):
             agent = PPO(make_args(4096, graph=graph, testing=True))
-            _run(agent, 2 * agent.rollout_size + 5)      # second pass over t replays captured graphs
+            T = agent.rollout_size
+            _run(agent, 3 * T)                           # rollout 1 eager, rollout 2 captures + replays, rollout 3 replays
         torch.cuda.synchronize()
         if graph:
-            assert len(agent._graphs) == agent.rollout_size
+            assert len(agent._graphs) == 1
         res[graph] = (agent._obs_ring.clone(), agent.all_acts.clone(), agent.all_reward.clone(),
-                      agent.all_log_prob.clone(), agent.env.progress_buf.clone(), float(agent.action_var[0]))
+                      agent.all_log_prob.clone(), agent.env.progress_buf.clone(), float(agent.action_var[0]), agent._score_acc.clone())
+        # rows the host has stepped through are final mid-rollout too: 7 more steps, compare those rows
+        with contextlib.redirect_stdout(io.StringIO()):
+            _run(agent, 7)
+        torch.cuda.synchronize()
+        res[graph] += (agent.all_acts[:7].clone(), agent.all_log_prob[:7].clone(), agent._obs_ring[:8].clone(),
+                       float(agent.action_var[0]), agent.env.obs_buf.clone())
         agent.exit()
-    for a, b in zip(res[False][:5], res[True][:5]):
-        assert torch.equal(a, b)
-    assert res[False][5] == res[True][5]
+    for i, (a, b) in enumerate(zip(res[False], res[True])):
+        if torch.is_tensor(a):
+            assert torch.equal(a, b), i
+        else:
+            assert a == b, i
 
 
 @pytest.mark.parametrize("n", [33, 8192])
@@ -179,7 +191,7 @@ def test_fused_forward_sample_matches_separate_kernels(n):
     _lib.check(lib.ppo_sample_logprob(p(mu), p(var), p(eps), p(act1), p(lp1), n, None), "sample")
     act2 = torch.empty(n, 18, device="cuda:0"); lp2 = torch.empty(n, device="cuda:0"); mu2 = torch.empty(n, 18, device="cuda:0")
     v2 = torch.empty(n, device="cuda:0")
-    _lib.check(lib.mlp_forward_sample(p(pol.P), p(pol.PF), p(x), n, p(eps), p(var), 0, 0.0, 0.0, p(act2), p(lp2), p(mu2), p(v2), pol.infer_pb_ptr(), None), "fused")
+    _lib.check(lib.mlp_forward_sample(p(pol.P), p(pol.PF), p(x), n, p(eps), p(var), 0, 0.0, 0.0, p(act2), p(lp2), p(mu2), p(v2), pol.infer_pb_ptr(), None, None), "fused")
     torch.cuda.synchronize()
     assert torch.equal(mu, mu2) and torch.equal(act1, act2) and torch.equal(v1.view(-1), v2)
     torch.testing.assert_close(lp1, lp2, rtol=2e-6, atol=1e-5)
@@ -234,10 +246,12 @@ def test_rollout_bookkeeping_equals_per_step_calls():
                                                 C.c_float(0.01), None), "step")
         s2 = torch.full((), 0.25, device="cuda:0"); v2 = torch.full((18,), v0, device="cuda:0")
         terms = torch.zeros(rows, device="cuda:0")
+        applied = torch.full((1,), 5, dtype=torch.int32, device="cuda:0")
         _lib.check(lib.ppo_rollout_bookkeeping(p(reward), rows, n, p(terms), p(s2), C.c_float(0.01), p(v2), 18,
-                                               C.c_float(dec), C.c_float(0.01), None), "rollout")
+                                               C.c_float(dec), C.c_float(0.01), p(applied), None), "rollout")
         torch.cuda.synchronize()
         assert torch.equal(s1, s2) and torch.equal(v1, v2)
+        assert int(applied) == 5 + rows                      # the word the policy launches subtract from their row index
     assert float(v2[0]) == float(np.float32(0.2))            # dec = 0: untouched
 
 

@@ -43,7 +43,7 @@ a_o = torch.empty(N, 18, device="cuda:0"); lp_o = torch.empty(N, device="cuda:0"
 pp = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
 for _ in range(REPS):      # the loop's one-launch env step
     lib.ppo_rollout_step(env._handle, C.byref(env._bufs), pp(pol.P), pp(pol.PF), pp(xs), pp(eps), pp(var), 0, 0.0, 0.0,
-                         pp(a_o), pp(lp_o), pp(v_o), pol.infer_pb_ptr(), None)
+                         pp(a_o), pp(lp_o), pp(v_o), pol.infer_pb_ptr(), None, None)
 with torch.no_grad():
     for _ in range(REPS):
         pol.forward(xs, want_mu=True, want_v=False)
