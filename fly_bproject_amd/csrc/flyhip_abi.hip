@@ -53,7 +53,7 @@ extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PF, float* PT, con
                                              float* v, int* step, float lr, float beta1, float beta2, float eps,
                                              float max_norm, float grad_scale, float* norm_ws, int norm_ready,
                                              uint16_t* PB, uint16_t* PTB, const int* idx_fb, const int* idx_tb,
-                                             void* stream);
+                                             int* step_out, void* stream);
 
 extern "C" hipError_t flyhip_launch_bookkeeping(const float* reward, int64_t n, float* score_acc, float score_scale,
                                                 float* action_var, int nvar, float var_decay, float var_min,
@@ -372,7 +372,7 @@ int mlp_adam_step(float* params, float* params_frag, float* params_t_frag, const
                   const int32_t* idx_t_frag, const float* grad, const float* mask, float* exp_avg,
                   float* exp_avg_sq, int32_t* step, float lr, float beta1, float beta2, float eps,
                   float max_norm, float grad_scale, float* norm_ws, int32_t norm_ready, uint16_t* params_b3,
-                  uint16_t* params_t_b3, const int32_t* idx_b3, const int32_t* idx_t_b3, void* stream)
+                  uint16_t* params_t_b3, const int32_t* idx_b3, const int32_t* idx_t_b3, int32_t* step_out, void* stream)
 {
     if (params_b3 && (!params_t_b3 || !idx_b3 || !idx_t_b3))
         return fail(FLY_E_ARG, "mlp_adam_step: params_b3 needs params_t_b3, idx_b3 and idx_t_b3");
@@ -381,7 +381,7 @@ int mlp_adam_step(float* params, float* params_frag, float* params_t_frag, const
         return fail(FLY_E_ARG, "mlp_adam_step: null pointer");
     hipError_t e = flyhip_launch_mlp_adam(params, params_frag, params_t_frag, idx_frag, idx_t_frag, grad, mask, exp_avg, exp_avg_sq, step, lr, beta1, beta2,
                                           eps, max_norm, grad_scale, norm_ws, norm_ready, params_b3, params_t_b3, idx_b3, idx_t_b3,
-                                          stream);
+                                          step_out, stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_adam_step launch");
     return FLY_OK;
 }

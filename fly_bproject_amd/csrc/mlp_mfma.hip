@@ -300,11 +300,13 @@ extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PF, float* PT, con
                                              float* v, int* step, float lr, float beta1, float beta2, float eps,
                                              float max_norm, float grad_scale, float* norm_ws, int norm_ready,
                                              uint16_t* PB, uint16_t* PTB, const int* idx_fb, const int* idx_tb,
-                                             void* stream)
+                                             int* step_out, void* stream)
 {
     int nparts = ADAM_BLOCKS;
     float part_scale = 1.0f;
-    if (norm_ready) {               // mlp_grad_w already left per-block sums of squares (unscaled) and advanced the step
+    if (step_out) {                 // one launch: the kernel sums the gradient itself and ping-pongs the step counter
+        part_scale = 1.0f;          // its sum is of the SCALED gradient
+    } else if (norm_ready) {               // mlp_grad_w already left per-block sums of squares (unscaled) and advanced the step
         nparts = RED_BLOCKS;
         part_scale = grad_scale * grad_scale;
     } else {
@@ -315,6 +317,6 @@ extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PF, float* PT, con
     }
     hipLaunchKernelGGL(mlp_adam_apply_kernel, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, P, PF, PT,
                        idx_f, idx_t, G, mask, m, v, step, lr, beta1, beta2, eps, max_norm, grad_scale, norm_ws, nparts,
-                       part_scale, PB, PTB, idx_fb, idx_tb);
+                       part_scale, PB, PTB, idx_fb, idx_tb, step_out);
     return hipGetLastError();
 }

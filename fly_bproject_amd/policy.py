@@ -258,7 +258,8 @@ class PackedPolicy:
         self.G = torch.zeros(PACKED, device=dev)
         self.exp_avg = torch.zeros(PACKED, device=dev)
         self.exp_avg_sq = torch.zeros(PACKED, device=dev)
-        self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._step2 = torch.zeros(2, dtype=torch.int32, device=dev)    # the step counter (two words: see adam_step)
+        self._step_idx = 0
         self.steps_issued = 0              # adam_step calls so far; the device counter lags iff a step was refused (fail closed)
         self._norm_ws = torch.zeros(1280, device=dev)      # [0] = pre-clip gradient norm, rest partial sums
         self.grad_norm = self._norm_ws[:1]
@@ -347,14 +348,28 @@ class PackedPolicy:
         parts = self.loss_part[: (n + 31) // 32].sum(0)
         return (parts[0] + parts[1]) / n
 
-    def adam_step(self, grad_scale=1.0, norm_ready=False):
+    @property
+    def step(self):
+        """Device int32 [1]: optimizer steps applied so far."""
+        return self._step2[self._step_idx:self._step_idx + 1]
+
+    def adam_step(self, grad_scale=1.0, norm_ready=False, self_norm=False):
+        """clip_grad_norm_ + Adam on the packed parameters.  norm_ready: mlp_grad_w has already left the norm
+        partials and advanced the step (single rank).  self_norm: ONE launch that also sums the gradient
+        (data-parallel ranks: G comes out of the all-reduce); the step counter then ping-pongs between two
+        device words so that no workgroup reads a value another one has already advanced."""
         p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
         self.version += 1
         self.steps_issued += 1
+        step_in = self.step
+        step_out = None
+        if self_norm:
+            self._step_idx ^= 1
+            step_out = p(self.step)
         _lib.check(self._lib.mlp_adam_step(p(self.P), p(self.PF), p(self.PT), p(self.idx_f), p(self.idx_t), p(self.G),
                                            p(self.grad_mask), p(self.exp_avg),
-                                           p(self.exp_avg_sq), p(self.step), C.c_float(self.lr),
+                                           p(self.exp_avg_sq), p(step_in), C.c_float(self.lr),
                                            C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
                                            C.c_float(self.max_norm), C.c_float(grad_scale), p(self._norm_ws),
-                                           C.c_int(1 if norm_ready else 0), *self._plane_args(), _lib.stream_ptr()),
+                                           C.c_int(1 if norm_ready else 0), *self._plane_args(), step_out, _lib.stream_ptr()),
                    "mlp_adam_step")

@@ -302,7 +302,8 @@ class PPO:
                                    fuse_norm=not sync_grads)
                 if sync_grads:
                     dist.all_reduce(pol.G, op=dist.ReduceOp.SUM)    # 297 KB, latency-bound on xGMI
-                pol.adam_step(grad_scale=1.0 / self.world_size if sync_grads else 1.0, norm_ready=not sync_grads)
+                pol.adam_step(grad_scale=1.0 / self.world_size if sync_grads else 1.0, norm_ready=not sync_grads,
+                              self_norm=sync_grads)       # either way ONE optimizer launch per step
 
         run(slices)
         # ONE host sync per update.  A fused forward+backward launch whose backward could not get a tile

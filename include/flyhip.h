@@ -280,7 +280,11 @@ int ppo_rollout_step(FlyHandle h, const FlyBuffers* b, const float* params, cons
  *                     512 and 1024 16-bit words later).  `mask` (packed layout, 0/1)
  *                     freezes padding and structural zeros.  `step` is a device int counter;
  *                     `norm_ws` is a device scratch of >= 1280 floats, norm_ws[0] returns the
- *                     pre-clip gradient norm.  FAIL CLOSED: with grad[76] != 0 (see mlp_grad_w) the
+ *                     pre-clip gradient norm.  step_out != NULL (data-parallel ranks, the gradient
+ *                     comes out of an all-reduce): ONE launch -- every workgroup sums the masked
+ *                     gradient itself (norm_ready is ignored) and the counter ping-pongs: *step is
+ *                     only read, *step_out = *step + 1 is written; pass the two words alternately.
+ *                     FAIL CLOSED: with grad[76] != 0 (see mlp_grad_w) the
  *                     call changes nothing -- parameters, moments and *step keep their values.
  */
 int64_t mlp_grad_workspace_floats(void);
@@ -326,7 +330,7 @@ int mlp_adam_step(float* params, float* params_frag, float* params_t_frag, const
                   float* exp_avg_sq, int32_t* step, float lr, float beta1, float beta2, float eps,
                   float max_norm, float grad_scale, float* norm_ws, int32_t norm_ready,
                   uint16_t* params_b3, uint16_t* params_t_b3, const int32_t* idx_b3,
-                  const int32_t* idx_t_b3, void* stream);
+                  const int32_t* idx_t_b3, int32_t* step_out, void* stream);
 
 
 /*

@@ -166,16 +166,24 @@ def test_fused_norm_step_matches_two_launch_step():
     """Single-rank fast path (clip-norm partials produced by the gradient reduce, one optimizer
     launch) vs the general path (separate norm launch): same norm, same parameters."""
     outs = []
-    for fused in (False, True):
+    for mode in ("two_launch", "fused_norm", "self_norm"):
         net, ref, pol, (x, action, old_logp, adv, target, var) = _setup(4099, 11)
         for it in range(3):
-            pol.minibatch_grad(x, action, old_logp, adv * (30.0 if it == 1 else 1.0), target, var, 0.2, fuse_norm=fused)
-            pol.adam_step(norm_ready=fused)
+            pol.minibatch_grad(x, action, old_logp, adv * (30.0 if it == 1 else 1.0), target, var, 0.2,
+                               fuse_norm=mode == "fused_norm")
+            # "self_norm": the data-parallel form -- ONE launch sums the (all-reduced) gradient itself, scales it by
+            # 1 / world (here: the gradient doubled first, scale 0.5) and ping-pongs the step counter
+            if mode == "self_norm":
+                pol.G.mul_(2.0)
+                pol.adam_step(grad_scale=0.5, self_norm=True)
+            else:
+                pol.adam_step(norm_ready=mode == "fused_norm")
         outs.append((pol.P.clone(), float(pol.grad_norm), int(pol.step), pol.PF.clone()))
-    assert outs[0][2] == outs[1][2] == 3
-    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-5)
-    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-7)
-    torch.testing.assert_close(outs[0][3], outs[1][3], rtol=1e-5, atol=1e-7)
+    assert outs[0][2] == outs[1][2] == outs[2][2] == 3
+    for o in outs[1:]:
+        np.testing.assert_allclose(outs[0][1], o[1], rtol=1e-5)
+        torch.testing.assert_close(outs[0][0], o[0], rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(outs[0][3], o[3], rtol=1e-5, atol=1e-7)
 
 
 @pytest.mark.parametrize("n", [16, 4099, 40960])
