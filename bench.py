@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_alt_gemm", action="store_true", help="skip the secondary bf16x3 measurement")
     ap.add_argument("--kernel_reps", type=int, default=200)
+    ap.add_argument("--dp_allreduce", choices=["auto", "rccl", "p2p"], default="auto",
+                    help="per-optimizer-step gradient exchange of N > 1 ranks: auto = the one-shot peer-to-peer kernel if its "
+                         "start-up self-test against RCCL passes on this node, else RCCL")
     ap.add_argument("--workload", choices=["ppo", "dqn"], default="ppo",
                     help="ppo (default, BASELINE's metric config) or dqn = BASELINE configs[4] (labelled line of its own)")
     ap.add_argument("--dqn_envs", type=int, default=32768)
@@ -384,7 +387,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     torch.manual_seed(0)
-    args = make_args(a.num_envs, sim_device=dev, rank=rank, world_size=world)
+    args = make_args(a.num_envs, sim_device=dev, rank=rank, world_size=world, dp_allreduce=a.dp_allreduce)
     with quiet():
         agent = PPO(args)
     broadcast_policy(agent)
@@ -451,6 +454,9 @@ def main():
         finally:
             agent.policy.gemm = main_gemm
     finite = all(torch.isfinite(p).all().item() for p in agent.net.parameters())
+    agent_exchange = {"p2p": "one-shot peer-to-peer kernel over hipIpc windows (dp_allreduce_p2p)",
+                      "rccl": "torch.distributed.all_reduce (%s)" % (os.environ.get("FLY_DIST_BACKEND") or "nccl = RCCL")}.get(
+        agent.dp_allreduce, agent.dp_allreduce)
     ep_ret, ep_len, ep_cnt = agent.env.episode_stats()
     agent.exit()
 
@@ -467,7 +473,9 @@ def main():
             "config": {"workload": "fly_ppo_iteration_%denvs_T%d" % (a.num_envs, T),
                        "num_envs_per_gpu": a.num_envs, "rollout_size": T, "optimizer_steps_per_iteration": 75,
                        "minibatch_samples": agent.mini_chunk_size * a.num_envs, "variant": "bigGrav",
-                       "parallelism": "dp%d" % world, "gemm": main_gemm},
+                       "parallelism": "dp%d" % world, "gemm": main_gemm,
+                       "grad_exchange": "none (1 rank)" if world == 1 else
+                       ("%s, one call per optimizer step (75 per iteration), 297 KB" % agent_exchange)},
             "rollout_only_env_steps_per_s": round(world * a.num_envs * T / rollout_s, 1),
             "params_finite": finite,
             "mean_episode_return": None if ep_cnt == 0 else round(ep_ret, 4),

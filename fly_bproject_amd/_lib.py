@@ -53,6 +53,12 @@ SYMBOLS = {
     "dqn_grad_workspace_floats": [],
     "dqn_grad_w": [_P] * 6 + [_L, _P, _P, _I, _P],
     "dqn_adam_soft_update": [_P] * 12 + [_F, _F, _F, _F, _F, _P],
+    "dp_p2p_alloc": [_L, C.POINTER(_P)],
+    "dp_p2p_free": [_P],
+    "dp_ipc_export": [_P, _P],
+    "dp_ipc_import": [_P, C.POINTER(_P)],
+    "dp_ipc_close": [_P],
+    "dp_allreduce_p2p": [_P, _L, C.POINTER(_P), _I, _I, C.c_uint32, _P, _P],
 }
 
 

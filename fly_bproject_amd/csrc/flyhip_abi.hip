@@ -2,6 +2,7 @@
 // Argument checking, handle lifetime and error strings live here; kernels live in fly_env.hip
 // and ppo_kernels.hip.  Nothing here synchronises the host or allocates caller tensors.
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -43,6 +44,9 @@ extern "C" hipError_t flyhip_launch_dqn_adam(float* P, float* PF, float* PT, flo
                                              const int* idx_t, const float* G, const float* mask, float* m, float* v,
                                              int* step, float lr, float beta1, float beta2, float eps, float tau,
                                              void* stream);
+extern "C" hipError_t flyhip_p2p_alloc(int64_t n_floats, void** out);
+extern "C" hipError_t flyhip_launch_p2p_allreduce(float* G, int64_t n, void* const* bases, int rank, int world,
+                                                  uint32_t epoch, int* err, void* stream);
 extern "C" int64_t flyhip_mlp_grad_workspace_floats(void);
 extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, const float* h2, const float* h3,
                                                const float* dz1, const float* dz2, const float* dz3, const float* dz4,
@@ -466,6 +470,66 @@ int dqn_adam_soft_update(float* params, float* params_frag, float* params_t_frag
     hipError_t e = flyhip_launch_dqn_adam(params, params_frag, params_t_frag, target_params, target_params_frag, idx_frag,
                                           idx_t_frag, grad, mask, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, tau, stream);
     if (e != hipSuccess) return hip_fail(e, "dqn_adam_soft_update launch");
+    return FLY_OK;
+}
+
+int dp_p2p_alloc(int64_t n_floats, void** window_out)
+{
+    if (!window_out || n_floats <= 0 || (n_floats & 3)) return fail(FLY_E_ARG, "dp_p2p_alloc: need a pointer and n_floats a positive multiple of 4");
+    hipError_t e = flyhip_p2p_alloc(n_floats, window_out);
+    if (e != hipSuccess) return hip_fail(e, "dp_p2p_alloc");
+    return FLY_OK;
+}
+
+int dp_p2p_free(void* window)
+{
+    if (!window) return FLY_OK;
+    hipError_t e = hipFree(window);
+    if (e != hipSuccess) return hip_fail(e, "dp_p2p_free");
+    return FLY_OK;
+}
+
+int dp_ipc_export(const void* window, uint8_t handle_out[64])
+{
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    if (!window || !handle_out) return fail(FLY_E_ARG, "dp_ipc_export: null pointer");
+    hipIpcMemHandle_t h;
+    hipError_t e = hipIpcGetMemHandle(&h, const_cast<void*>(window));
+    if (e != hipSuccess) return hip_fail(e, "hipIpcGetMemHandle");
+    memcpy(handle_out, &h, 64);
+    return FLY_OK;
+}
+
+int dp_ipc_import(const uint8_t handle[64], void** window_out)
+{
+    if (!handle || !window_out) return fail(FLY_E_ARG, "dp_ipc_import: null pointer");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, 64);
+    hipError_t e = hipIpcOpenMemHandle(window_out, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return hip_fail(e, "hipIpcOpenMemHandle");
+    return FLY_OK;
+}
+
+int dp_ipc_close(void* window)
+{
+    if (!window) return FLY_OK;
+    hipError_t e = hipIpcCloseMemHandle(window);
+    if (e != hipSuccess) return hip_fail(e, "hipIpcCloseMemHandle");
+    return FLY_OK;
+}
+
+int dp_allreduce_p2p(float* grad, int64_t n_floats, void* const* windows, int32_t rank, int32_t world, uint32_t epoch,
+                     int32_t* err, void* stream)
+{
+    if (!grad || !windows || !err) return fail(FLY_E_ARG, "dp_allreduce_p2p: null pointer");
+    if (world < 1 || world > 16 || rank < 0 || rank >= world) return fail(FLY_E_ARG, "dp_allreduce_p2p: bad rank / world (max 16)");
+    if (n_floats <= 0 || (n_floats & 3)) return fail(FLY_E_ARG, "dp_allreduce_p2p: n_floats must be a positive multiple of 4");
+    if (n_floats / 4 > 1024L * 256) return fail(FLY_E_ARG, "dp_allreduce_p2p: buffer too large for a co-resident grid");
+    if (epoch == 0) return fail(FLY_E_ARG, "dp_allreduce_p2p: epochs start at 1");
+    for (int r = 0; r < world; ++r)
+        if (!windows[r]) return fail(FLY_E_ARG, "dp_allreduce_p2p: window %d is null", r);
+    hipError_t e = flyhip_launch_p2p_allreduce(grad, n_floats, windows, rank, world, epoch, err, stream);
+    if (e != hipSuccess) return hip_fail(e, "dp_allreduce_p2p launch");
     return FLY_OK;
 }
 

@@ -41,6 +41,71 @@ class FlatGradAllReduce:
             self.flat.div_(self.world_size)
 
 
+class P2PAllReduce:
+    """One-shot peer-to-peer all-reduce (sum) of ONE flat fp32 device buffer across the ranks of a node
+    (`dp_allreduce_p2p`, csrc/dp_p2p.hip): every rank publishes its buffer in a fine-grained window the peers
+    have opened through hipIpc, and sums all windows in rank order -- one launch, one xGMI hop, bit-identical
+    results on every rank.  The window handles travel once, at construction, through torch.distributed
+    (any backend).  `allreduce_(t)` is asynchronous on the current stream; `check()` (a host sync) reports a
+    rank that never published (bounded wait), after which the caller falls back to dist.all_reduce."""
+
+    def __init__(self, n_floats, device, group=None):
+        import ctypes as C
+        from . import _lib
+        self._C, self._lib, self._libmod = C, _lib.load(), _lib
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.n = int(n_floats)
+        if self.n % 4 or self.world > 16:
+            raise ValueError("P2PAllReduce: n_floats must be a multiple of 4 and world <= 16")
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self._mine = C.c_void_p()
+        _lib.check(self._lib.dp_p2p_alloc(C.c_int64(self.n), C.byref(self._mine)), "dp_p2p_alloc")
+        handle = (C.c_uint8 * 64)()
+        _lib.check(self._lib.dp_ipc_export(self._mine, handle), "dp_ipc_export")
+        handles = [None] * self.world
+        dist.all_gather_object(handles, bytes(handle), group=group)
+        self._windows = (C.c_void_p * self.world)()
+        self._opened = []
+        for r, h in enumerate(handles):
+            if r == self.rank:
+                self._windows[r] = self._mine.value
+            else:
+                ptr = C.c_void_p()
+                buf = (C.c_uint8 * 64).from_buffer_copy(h)
+                _lib.check(self._lib.dp_ipc_import(buf, C.byref(ptr)), "dp_ipc_import (rank %d)" % r)
+                self._windows[r] = ptr.value
+                self._opened.append(ptr)
+        self.err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.epoch = 0
+        dist.barrier(group=group)                                  # every window is open before anybody publishes
+
+    def allreduce_(self, t):
+        assert t.is_contiguous() and t.dtype == torch.float32 and t.numel() == self.n and t.device == self.device
+        self.epoch += 1
+        C = self._C
+        self._libmod.check(self._lib.dp_allreduce_p2p(C.c_void_p(t.data_ptr()), C.c_int64(self.n), self._windows, self.rank,
+                                                      self.world, C.c_uint32(self.epoch), C.c_void_p(self.err.data_ptr()),
+                                                      self._libmod.stream_ptr()), "dp_allreduce_p2p")
+        return t
+
+    def check(self):
+        """Host sync: True if every all-reduce since the last check saw all ranks."""
+        bad = int(self.err.item())
+        if bad:
+            self.err.zero_()
+        return bad == 0
+
+    def close(self):
+        if self._mine:
+            torch.cuda.synchronize(self.device)
+            for ptr in self._opened:
+                self._lib.dp_ipc_close(ptr)
+            self._opened = []
+            self._lib.dp_p2p_free(self._mine)
+            self._mine = self._C.c_void_p()
+
+
 def init_from_env(device_type="cuda"):
     """Read RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* (torch.distributed.run) and join the group."""
     rank = int(os.environ.get("RANK", "0"))

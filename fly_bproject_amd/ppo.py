@@ -150,6 +150,13 @@ class PPO:
         self.dp_mode = getattr(args, "dp_mode", "grad_allreduce")
         if self.dp_mode not in ("grad_allreduce", "param_average"):
             raise ValueError("dp_mode must be grad_allreduce or param_average")
+        # the per-step gradient exchange: "rccl" = torch.distributed.all_reduce (RCCL over xGMI; the default and the
+        # fallback) or "p2p" = the one-shot peer-to-peer kernel of csrc/dp_p2p.hip (one node, <= 16 ranks)
+        # "auto" = p2p if its start-up self-test against the collective passes on this node, else rccl.
+        self.dp_allreduce = getattr(args, "dp_allreduce", None) or os.environ.get("FLY_DP_ALLREDUCE", "rccl")
+        if self.dp_allreduce not in ("rccl", "p2p", "auto"):
+            raise ValueError("dp_allreduce must be rccl, p2p or auto")
+        self._p2p = None
         self._flat_grad = None
         if self.world_size > 1:
             from .dist import FlatGradAllReduce
@@ -293,6 +300,8 @@ class PPO:
         pol = self.policy
         sync_grads = self.world_size > 1 and self.dp_mode == "grad_allreduce"
         slices = [(j - mc, j) for _ in range(self.epoch) for j in range(mc, self.rollout_size, mc)]   # 5 x 15 (Q3)
+        if sync_grads and self.dp_allreduce in ("p2p", "auto") and self._p2p is None:
+            self._p2p = self._open_p2p(pol.G.numel())
 
         def run(todo):
             for k, j in todo:
@@ -301,7 +310,10 @@ class PPO:
                                    target[k:j].view(rows), self._action_var, self.clip,
                                    fuse_norm=not sync_grads)
                 if sync_grads:
-                    dist.all_reduce(pol.G, op=dist.ReduceOp.SUM)    # 297 KB, latency-bound on xGMI
+                    if self._p2p is not None:
+                        self._p2p.allreduce_(pol.G)                 # one launch, one xGMI hop, sum in rank order
+                    else:
+                        dist.all_reduce(pol.G, op=dist.ReduceOp.SUM)    # 297 KB, latency-bound on xGMI
                 pol.adam_step(grad_scale=1.0 / self.world_size if sync_grads else 1.0, norm_ready=not sync_grads,
                               self_norm=sync_grads)       # either way ONE optimizer launch per step
 
@@ -325,6 +337,8 @@ class PPO:
                   "could not get its tile); redoing them with two launches" % (short, len(slices)))
             run(slices[len(slices) - short:])
         self.optim_step += len(slices)
+        if self._p2p is not None and not self._p2p.check():
+            raise _lib.FlyHipError("dp_allreduce_p2p: a rank never published its gradient (bounded wait expired)")
         if self.world_size > 1 and not sync_grads:
             # dp_mode "param_average": ONE exchange per PPO update (BASELINE's north_star wording) --
             # ranks take their 75 optimizer steps locally, then parameters and Adam moments are
@@ -333,6 +347,45 @@ class PPO:
                 dist.all_reduce(buf, op=dist.ReduceOp.SUM)
                 buf.div_(self.world_size)
             pol.refresh()
+
+    def _open_p2p(self, n):
+        """Open the peer windows and hold the one-shot kernel to the collective on random data (3 epochs, both
+        parities).  Every rank takes the same decision (the verdicts are all-reduced): on any failure -- no IPC
+        between these devices, a rank that never publishes, a wrong sum -- "auto" falls back to RCCL, "p2p" raises."""
+        import torch.distributed as dist
+        from .dist import P2PAllReduce
+        ok, p2p, why = 1, None, ""
+        try:
+            p2p = P2PAllReduce(n, self.device)
+        except Exception as e:      # noqa: BLE001
+            ok, why = 0, repr(e)[:200]
+        flag = torch.tensor([ok], device=self.device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            gen = torch.Generator(device=self.device)
+            gen.manual_seed(7 + int(getattr(self.args, "rank", 0)))
+            for _ in range(3):
+                a = torch.randn(n, device=self.device, generator=gen)
+                b = a.clone()
+                p2p.allreduce_(a)
+                dist.all_reduce(b, op=dist.ReduceOp.SUM)
+                good = p2p.check() and torch.allclose(a, b, rtol=1e-5, atol=1e-5)
+                flag.fill_(1 if good else 0)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) != 1:
+                    why = "self-test against the collective failed"
+                    break
+        if int(flag.item()) == 1:
+            self.dp_allreduce = "p2p"
+            return p2p
+        if p2p is not None:
+            p2p.close()
+        if self.dp_allreduce == "p2p":
+            raise _lib.FlyHipError("dp_allreduce=p2p is not usable on this node: %s" % (why or "a peer failed"))
+        if int(getattr(self.args, "rank", 0)) == 0:
+            print("dp_allreduce auto: peer-to-peer all-reduce unavailable (%s); using the RCCL collective" % (why or "a peer failed"))
+        self.dp_allreduce = "rccl"
+        return None
 
     # ------------------------------------------------------------------------------------------
     def _prepare_step_args(self):
@@ -485,4 +538,7 @@ class PPO:
         self.env.generate_video()
 
     def exit(self):
+        if self._p2p is not None:
+            self._p2p.close()
+            self._p2p = None
         self.env.exit()

@@ -391,6 +391,25 @@ int dqn_adam_soft_update(float* params, float* params_frag, float* params_t_frag
                          float lr, float beta1, float beta2, float eps, float tau, void* stream);
 
 
+/*
+ * One-shot peer-to-peer all-reduce (sum) of the packed gradient across the data-parallel ranks of ONE node, in
+ * place of torch.distributed.all_reduce (RCCL) between mlp_grad_w and mlp_adam_step -- the call that stands where
+ * the reference's single-process update has nothing to exchange (ppo.py:196-199).  Every rank allocates a
+ * fine-grained window (dp_p2p_alloc: 2 x n_floats of publish space + flags), exports it (dp_ipc_export, 64 opaque
+ * bytes to hand to the peers by any means), opens the peers' (dp_ipc_import) and passes the `world` window
+ * pointers -- its own at index `rank` -- in rank order.  dp_allreduce_p2p(grad, ...) with epoch = 1, 2, 3, ...
+ * (the same on every rank): one launch publishes grad, waits for every rank's flag of this epoch (bounded:
+ * *err = 1 instead of a hang) and leaves the sum over ranks, added in rank order (bit-identical on every rank),
+ * in grad.  world <= 16.
+ */
+int dp_p2p_alloc(int64_t n_floats, void** window_out);
+int dp_p2p_free(void* window);
+int dp_ipc_export(const void* window, uint8_t handle_out[64]);
+int dp_ipc_import(const uint8_t handle[64], void** window_out);
+int dp_ipc_close(void* window);
+int dp_allreduce_p2p(float* grad, int64_t n_floats, void* const* windows, int32_t rank, int32_t world,
+                     uint32_t epoch, int32_t* err, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

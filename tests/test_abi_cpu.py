@@ -19,7 +19,7 @@ def built():
 def _declared_symbols():
     text = open(os.path.join(REPO, "include", "flyhip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"\b(?:int|int64_t|const char\s*\*)\s+((?:fly|ppo|mlp|dqn)_\w+)\s*\(", text)
+    names = re.findall(r"\b(?:int|int64_t|const char\s*\*)\s+((?:fly|ppo|mlp|dqn|dp)_\w+)\s*\(", text)
     assert len(names) >= 12
     return names
 

@@ -21,6 +21,43 @@ def _free_port():
     return p
 
 
+def _p2p_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    from fly_bproject_amd.dist import P2PAllReduce
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    n = 74272
+    ar = P2PAllReduce(n, "cuda:0")
+    outs = []
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(100 + rank)
+    for it in range(40):                                   # many epochs: both parities, back-to-back launches, no host sync
+        g = torch.randn(n, device="cuda:0", generator=gen) * (1.0 + it)
+        mine = g.clone()
+        ar.allreduce_(g)
+        if it % 3 == 0:
+            torch.cuda._sleep(200000 * (rank + 1))         # uneven arrival
+        outs.append((mine.cpu(), g.cpu()))
+    assert ar.check()
+    torch.save(outs, os.path.join(out_dir, "p2p%d.pt" % rank))
+    dist.barrier()
+    ar.close()
+    dist.destroy_process_group()
+
+
+def test_p2p_allreduce_two_ranks_one_gpu(tmp_path):
+    """dp_allreduce_p2p between two processes (both on cuda:0, windows exchanged through hipIpc): after every
+    epoch both ranks hold the sum of the two inputs, added in rank order, bit for bit -- 40 epochs back to back
+    with uneven arrival.  (Exercises the protocol and the IPC plumbing; the xGMI leg needs a multi-GPU node.)"""
+    port = _free_port()
+    mp.spawn(_p2p_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(tmp_path / "p2p0.pt", weights_only=True)
+    b = torch.load(tmp_path / "p2p1.pt", weights_only=True)
+    for (mine0, out0), (mine1, out1) in zip(a, b):
+        want = (torch.zeros_like(mine0) + mine0) + mine1    # rank order, starting from 0
+        assert torch.equal(out0, want) and torch.equal(out1, want)
+
+
 def _worker(rank, world, port, out_dir, dp_mode="grad_allreduce"):
     sys.path.insert(0, REPO)
     import contextlib
@@ -32,7 +69,9 @@ def _worker(rank, world, port, out_dir, dp_mode="grad_allreduce"):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     torch.manual_seed(10 + rank)                      # different init per rank: the broadcast must fix it
     with contextlib.redirect_stdout(io.StringIO()):
-        agent = PPO(make_args(2048, rank=rank, world_size=world, seed=0, dp_mode=dp_mode))
+        p2p = dp_mode == "p2p"
+        agent = PPO(make_args(2048, rank=rank, world_size=world, seed=0, dp_mode="grad_allreduce" if p2p else dp_mode,
+                              dp_allreduce="p2p" if p2p else "rccl"))
         broadcast_policy(agent)
         for _ in range(agent.rollout_size):
             agent.run()
@@ -45,7 +84,7 @@ def _worker(rank, world, port, out_dir, dp_mode="grad_allreduce"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dp_mode", ["grad_allreduce", "param_average"])
+@pytest.mark.parametrize("dp_mode", ["grad_allreduce", "param_average", "p2p"])
 def test_two_ranks_one_gpu(tmp_path, dp_mode):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path), dp_mode), nprocs=2, join=True)
@@ -54,6 +93,12 @@ def test_two_ranks_one_gpu(tmp_path, dp_mode):
     assert a["finite"] and b["finite"]
     assert torch.equal(a["P"], b["P"]) and torch.equal(a["PF"], b["PF"])     # replicas in lock step
     assert not torch.equal(a["acts"], b["acts"])                              # but different rollouts
+    if dp_mode == "p2p":        # the one-shot kernel sums in rank order like gloo's two-rank sum: same parameters as the collective
+        ref = torch.load(tmp_path.parent / "ref_P.pt", weights_only=True) if (tmp_path.parent / "ref_P.pt").exists() else None
+        if ref is not None:
+            assert torch.equal(a["P"], ref)
+    elif dp_mode == "grad_allreduce":
+        torch.save(a["P"], tmp_path.parent / "ref_P.pt")
 
 
 def test_bench_gpus_2_on_one_gpu():
