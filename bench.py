@@ -86,17 +86,22 @@ def quiet():
 
 
 def _time_launches(fn, reps):
-    """Average duration of `fn` (one kernel launch) from HIP events on the launch stream."""
-    for _ in range(10):
+    """Average duration of `fn` (one kernel launch) from HIP events on the launch stream: three batches of `reps`
+    back-to-back launches after a warm-up, the MEDIAN batch average (the first batch of a process also pays the
+    clock ramp: 114 vs 100 us on the same launch)."""
+    for _ in range(20):
         fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / reps
+    out = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1) * 1e-3 / reps)
+    return sorted(out)[1]
 
 
 # algorithmic work per unit (DESIGN.md section 3): bytes per env-step / FLOP per sample
@@ -158,7 +163,21 @@ def kernel_rooflines(num_envs, T, reps):
     t_gw = _time_launches(lambda: lib.mlp_grad_w(p(x), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(d["dz1"]), p(d["dz2"]),
                                                  p(d["dz3"]), p(d["dz4"]), rows, p(pol.workspace), p(pol.G), None, None, None,
                                                  None, 1 if pol.gemm == "bf16x3" else 0, _lib.stream_ptr()), reps)
-    t_adam = _time_launches(lambda: pol.adam_step(), reps)
+    # the optimizer launch is ~5 us: timed back to back it would read the HOST's launch rate (~10 us per ctypes call),
+    # so it is captured once into a hipGraph of 20 launches and the replay is timed
+    g = torch.cuda.CUDAGraph()
+    pol.adam_step(norm_ready=True)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        for _ in range(20):
+            pol.adam_step(norm_ready=True)
+    t_adam = _time_launches(g.replay, max(5, reps // 20)) / 20
+    # TD target + GAE over the whole rollout (ppo.py:157-171): 20 B per element (read r, v, v_next; write target, adv)
+    Tn = T * num_envs
+    rw = torch.randn(T, num_envs, device="cuda:0"); vv = torch.randn(T + 1, num_envs, device="cuda:0")
+    dn = torch.ones(num_envs, device="cuda:0"); tg_o = torch.empty(T, num_envs, device="cuda:0"); ad_o = torch.empty_like(tg_o)
+    t_gae = _time_launches(lambda: lib.ppo_td_gae(p(rw), p(vv[:T]), p(vv[1:]), p(dn), C.c_float(0.99), C.c_float(0.95), T,
+                                                  num_envs, p(tg_o), p(ad_o), 0, _lib.stream_ptr()), reps)
 
     def hbm(name, dur, bytes_per_launch, per_iter):
         ach = bytes_per_launch / dur / 1e9
@@ -187,8 +206,26 @@ def kernel_rooflines(num_envs, T, reps):
         # the forward body alone at num_envs rows: once per iteration for v(last next_obs)
         mfma("mlp_forward_kernel (policy + sample, %d rows)" % num_envs, t_pol, MLP_FWD_FLOP * num_envs, 1),
         mfma("mlp_grad_w_kernel (+reduce)", t_gw, MLP_GRAD_W_FLOP * rows, 75),
-        hbm("mlp_adam_kernel", t_adam, 74272 * 4 * 7, 75),
+        hbm("mlp_adam_apply_kernel (clip + Adam + fragment refresh)", t_adam, 74272 * 4 * 10, 75),
+        hbm("ppo_td_gae_kernel (T=%d x %d envs)" % (T, num_envs), t_gae, 20 * Tn, 1),
     ]
+    # the env kernel's REAL bound is vector-instruction issue, not HBM: instructions per wave (committed PMC pass,
+    # profiles/*_valu.json) x 4 issue cycles at one wave per SIMD, against the measured launch
+    try:
+        import glob
+        vf = sorted(glob.glob(os.path.join(REPO, "profiles", "*_valu.json")))
+        if vf:
+            vj = json.load(open(vf[-1]))
+            ipw = vj["fly_kernel<63>"]["valu_insts_per_wave"]
+            clk = vj.get("clock_ghz", 2.1)
+            floor_us = ipw * 4 / (clk * 1e3)
+            for k in ks:
+                if k["kernel"].startswith("fly_kernel<63>"):
+                    k["valu_roofline"] = {"bound": "valu-issue", "valu_insts_per_wave": ipw, "issue_cycles_per_inst": 4,
+                                          "waves_per_simd": 1, "clock_ghz": clk, "floor_us": round(floor_us, 2),
+                                          "frac": round(floor_us / (t_step * 1e6), 4), "source": os.path.basename(vf[-1])}
+    except Exception:
+        pass
     # HBM bytes per launch from the committed PMC passes (profiles/*_traffic.json, produced by
     # tools/summarize_pmc.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of the same kernels)
     traffic = {}

@@ -10,7 +10,7 @@
 //     lanes 0..5   one leg each: 3 PD joints, leg kinematics, tip contact        (contact pass A)
 //     lanes 0..4   ALSO one abdomen contact point each                          (contact pass B)
 //     lanes 6..7   idle in the contact passes (they still hold the replicated root state)
-// The kernel is VALU-issue-bound (15 substeps x ~400 instructions per wave), so what counts is
+// The kernel is VALU-issue-bound (15 substeps x ~330 instructions per wave), so what counts is
 // instructions per env: the contact code runs twice per substep, but a wave now advances 8 envs
 // instead of 4 -- 1.5x fewer instructions per env-substep than one point per lane on 16 lanes
 // (11 of 16 lanes busy, root integration replicated 16x).
@@ -20,7 +20,7 @@
 // All role differences are selects, not branches: a wave never diverges inside the substep loop.
 // Substeps run in registers; HBM is touched once on the way in and once on the way out.
 // Observation rows (row-major [N][73], a GEMM operand for the policy) are assembled in an LDS
-// tile and written as one contiguous 16x73 block per workgroup with 16-byte stores.
+// tile and written as one contiguous 32x73 block per workgroup with 16-byte stores.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>

@@ -24,8 +24,8 @@
  *   - Not re-entrant per handle: callers serialise calls on one handle.
  *
  * HBM layout: env-major records — every per-env record is contiguous, exactly the shapes the
- * reference's Isaac Gym tensors had, so the 16 lanes that own one env (fly_env.hip) touch one
- * or two cache lines per field and a wave (4 envs) reads a contiguous span:
+ * reference's Isaac Gym tensors had, so the 8 lanes that own one env (fly_env.hip) touch one
+ * or two cache lines per field and a wave (8 envs) reads a contiguous span:
  *   root      f32 [N][13]    pos xyz | quat xyzw | linvel xyz | angvel xyz   (fly.py:95-100)
  *   dof_state f32 [N][18][2] (pos, vel) per DoF, sim DoF order               (fly.py:89-90, :393)
  *   targets   f32 [N][18]    PD position targets = scaled actions (fly.py:636 `self.actions`)
