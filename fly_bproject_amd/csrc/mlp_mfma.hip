@@ -156,7 +156,7 @@ extern "C" hipError_t flyhip_launch_mlp_backward_dx(const float* PT, const float
 // (3 and 4) get more workgroups than their FLOP share: measured best of a dozen splits at 1280 tiles
 static int kGradWgs[4] = {80, 100, 52, 24};
 // the bf16x3 kernel (grad_w_b3.inc) pays a fixed staging + barrier cost per 16-row chunk, so its thin layers get
-// fewer rows each than their FLOP share: measured best of six splits at 1280 tiles (72 vs 82 us with the fp32 split)
+// the kernel streams: a CU pulls ~22 GB/s, so the split follows each layer's BYTES (54 / 63 / 42 / 26 MB), not its FLOPs
 static int kGradWgsB3[4] = {72, 88, 64, 32};
 static bool gw_env_read = false;
 static void gw_read_env()
@@ -273,8 +273,11 @@ extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, 
         attr_set = true;
     }
     if (gemm_b3) {
-        // two buffers of three bf16 term planes of a 16-row chunk: 2 x 3 x 16 x (288 + 160) x 2 B = 84 KiB
-        const size_t b3_bytes = 2 * 3 * GB_ROWS * (gb_pitch<MLP_H1>() + gb_pitch<MLP_H2>()) * sizeof(u16);
+        // two buffers of three bf16 term planes of a chunk: layers 1 / 2 stage 16 rows x (288 + 160) columns (84 KiB),
+        // layer 3 32 rows x (160 + 160) (120 KiB, the largest), layer 4 32 rows x (32 + 160) (72 KiB)
+        const size_t b3_bytes = 2 * 3 * GB_ROWS_L3 * 2 * gb_pitch<MLP_H3>() * sizeof(u16);
+        static_assert(16 * (gb_pitch<MLP_H1>() + gb_pitch<MLP_H2>()) <= GB_ROWS_L3 * 2 * gb_pitch<MLP_H3>() &&
+                      GB_ROWS_L4 * (gb_pitch<MLP_OUT>() + gb_pitch<MLP_H3>()) <= GB_ROWS_L3 * 2 * gb_pitch<MLP_H3>(), "layer 3's chunk is the largest");
         static bool b3_attr_set = false;
         if (!b3_attr_set) {
             hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_grad_w_b3_kernel),
