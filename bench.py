@@ -462,7 +462,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, rollout_s = float(tt[0]), float(tt[1])
     assert agent.optim_step == 75 * (a.warmup + a.steps), agent.optim_step
-    # Secondary, clearly labelled measurement: the same iteration with the update's forward + dX GEMMs
+    # Secondary, clearly labelled measurement (BASELINE configs[2]'s arithmetic): the same iteration with every MLP GEMM
     # on the bf16 matrix pipe through three-term operand splits (fp32-accurate: tools/bf16x3_gemm.hip,
     # tests/test_mlp_train_gpu.py::test_bf16x3_training_step_matches_fp32_path).  `value` above is the
     # default fp32-MFMA path.
@@ -482,8 +482,8 @@ def main():
                 tt = torch.tensor([alt_s], device=dev, dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 alt_s = float(tt[0])
-            alt = {"gemm": "bf16x3 (three-term bf16 split of both operands, six product terms, fp32 accumulate) for the "
-                           "update's forward and dX chain; dW, inference and everything else unchanged",
+            alt = {"gemm": "bf16x3 (three-term bf16 split of both operands, six product terms, fp32 accumulate) for EVERY MLP GEMM: "
+                           "rollout policy, critic pass, the update's forward, dX chain and dW",
                    "value": round(world * a.num_envs * T * 2 / alt_s, 1), "unit": "env-steps/s", "steps": 2,
                    "ms_per_step": round(alt_s / 2 * 1e3, 3)}
         except Exception as e:      # noqa: BLE001

@@ -4,6 +4,8 @@
 # Summarise afterwards with: python tools/summarize_pmc.py TAG gpurun_out/TAG/stats gpurun_out/TAG/pmc_*
 set -e
 TAG=${1:-prof}
+shift || true
+for kv in "$@"; do export "$kv"; done      # e.g. FLY_GEMM=bf16x3
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
@@ -19,6 +21,8 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_
 echo "sq2 done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline > $OUT/bench_stats.log 2>&1
 echo "bench stats done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dqn_stats -- python3 bench.py --workload dqn --steps 3 --warmup 1 --dqn_mini_batch 16 --kernel_reps 10 > $OUT/dqn_stats.log 2>&1
+echo "dqn bench stats done"
 # keep only the small per-kernel files (traces are large)
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*agent_info.csv" -delete

@@ -49,4 +49,16 @@ with torch.no_grad():
         pol.forward(xs, want_mu=True, want_v=False)
 torch.cuda.synchronize()
 env.exit()
+if os.environ.get("PROF_DQN", "1") != "0":          # configs[4]: one sampled replay step of 32768 rows through the DQN kernels
+    from fly_bproject_amd.dqn import DQN
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        agent = DQN(make_args(32768, dqn_mini_batch_size=4, replay_steps=8))
+        for _ in range(6):
+            agent.run()
+        for _ in range(REPS // 4 + 1):
+            agent.update()
+    torch.cuda.synchronize()
+    agent.exit()
 print("done")
