@@ -291,7 +291,7 @@ def test_fused_equals_unfused_bit_exact():
     fused.exit(); split.exit()
 
 
-@pytest.mark.parametrize("n", [8192, 8190, 4099])
+@pytest.mark.parametrize("n", [8192, 8190, 4099, 16384])
 def test_full_size_properties(n):
     """BASELINE size (8192 envs) and ragged tails: determinism, env-permutation equivariance
     (envs are independent: permuting the batch permutes every output bit-exactly), identical
