@@ -198,3 +198,76 @@ def test_physics_f32_vs_f64_tolerance():
             np.testing.assert_allclose(s2.root[:, 7:], r64[:, 7:], rtol=5e-3, atol=5e-3)
             np.testing.assert_allclose(s2.dof_pos, q64, rtol=2e-4, atol=2e-4)
     assert np.isfinite(s.root).all()
+
+
+# ---- property tests: the GAE recurrence and the DQN / replay host logic -------------------
+def test_gae_recurrence_properties():
+    """ppo.py:157-171 as the oracle restates it, against an independent float64 evaluation of the recurrence
+    adv_t = gamma*lambda*adv_{t+1} + delta_t (adv_T = 0, NO reset at episode ends: Q2) on random shapes, plus its
+    structural properties: linearity in the rewards and independence of the envs."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(1, 70), st.integers(1, 33), st.integers(0, 2 ** 31 - 1))
+    def check(T, n, seed):
+        rng = np.random.default_rng(seed)
+        r = rng.normal(size=(T, n)).astype(np.float32)
+        v = rng.normal(size=(T, n)).astype(np.float32)
+        vn = rng.normal(size=(T, n)).astype(np.float32)
+        done = (rng.random(n) > 0.3).astype(np.float32)                    # Q1: ONE [N] mask, broadcast over T
+        target, adv = O.td_gae(r, v, vn, done)
+        t64 = r.astype(np.float64) + 0.99 * vn.astype(np.float64) * done
+        delta = t64 - v
+        ref = np.zeros((T, n))
+        acc = np.zeros(n)
+        for t in range(T - 1, -1, -1):
+            acc = 0.99 * 0.95 * acc + delta[t]
+            ref[t] = acc
+        np.testing.assert_allclose(target, t64, rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(adv, ref, rtol=1e-5, atol=1e-5 * max(1.0, np.abs(ref).max()))
+        # envs are independent: a column of the batch alone gives that column
+        j = int(rng.integers(0, n))
+        t1, a1 = O.td_gae(r[:, j:j + 1].copy(), v[:, j:j + 1].copy(), vn[:, j:j + 1].copy(), done[j:j + 1].copy())
+        assert np.array_equal(t1[:, 0], target[:, j]) and np.array_equal(a1[:, 0], adv[:, j])
+        # linear in (r, v, v_next): doubling all three doubles both outputs exactly (powers of two are exact)
+        t2, a2 = O.td_gae(2 * r, 2 * v, 2 * vn, done)
+        assert np.array_equal(t2, 2 * target) and np.array_equal(a2, 2 * adv)
+    check()
+
+
+def test_dqn_packed_layout_maps():
+    """Host-side layout logic of the DQN Q-network (fly_bproject_amd/dqn.py, csrc/dqn_layout.h): the fragment index
+    maps are injective and cover their buffers exactly; layer 3's forward map is the split-K order the kernel reads."""
+    from fly_bproject_amd import dqn as D
+    idx_f, idx_t = D.build_index_maps()
+    assert (idx_f >= 0).sum() == D.FRAG == 94208 and (idx_t >= 0).sum() == D.FRAG_T == 73728
+    assert D.PACKED == 94752
+    for idx, size in ((idx_f, D.FRAG), (idx_t, D.FRAG_T)):
+        used = idx[idx >= 0]
+        assert len(np.unique(used)) == len(used) and used.min() == 0 and used.max() == size - 1
+    # biases have no fragment copy
+    for off, n in ((D.OFF_B1, D.H), (D.OFF_B2, D.H), (D.OFF_B3, D.OUT)):
+        assert np.all(idx_f[off:off + n] == -1) and np.all(idx_t[off:off + n] == -1)
+    # W3[n][k] -> ((w*8 + kq)*64 + (h*32 + n))*4 + q with k = 64 w + 32 h + 4 kq + q
+    n, k = 5, 64 * 2 + 32 * 1 + 4 * 3 + 2
+    assert idx_f[D.OFF_W3 + n * D.H + k] == D.OFF_F3 + ((2 * 8 + 3) * 64 + (1 * 32 + n)) * 4 + 2
+
+
+def test_replay_ring_sampling_logic():
+    """replay.py:10-31 as a ring: capacity in STEPS, wrap-around, distinct sampled slots, host-side draw."""
+    import torch
+    from fly_bproject_amd.dqn import ReplayBuffer
+    rb = ReplayBuffer(num_envs=4, num_obs=73, device="cpu", buffer_limit=5, seed=3)
+    assert rb.capacity == 5 and rb.bytes == 5 * 4 * (2 * 73 + 3) * 4
+    for i in range(8):
+        o = torch.full((4, 73), float(i))
+        rb.push(o, torch.full((4,), float(i)), torch.full((4,), float(i)), o + 0.5, torch.ones(4))
+    assert rb.size() == 5 and rb.head == 3
+    held = sorted(float(rb.action[s][0]) for s in range(5))
+    assert held == [3.0, 4.0, 5.0, 6.0, 7.0]                                   # the five newest steps
+    slots = rb.sample_slots(4)
+    assert len(set(slots)) == 4 and all(0 <= s < 5 for s in slots)
+    chunks = rb.sample(3)
+    assert len(chunks) == 3 and all(c[0].shape == (4, 73) and c[0].data_ptr() >= rb.obs.data_ptr() for c in chunks)   # views, no copy
+    big = ReplayBuffer(num_envs=32768, num_obs=73, device="meta", buffer_limit=None)
+    assert big.capacity == 512 and abs(big.bytes / 1e9 - 10.0) < 0.01        # the stated default: 512 steps = 10.0 GB
