@@ -378,7 +378,7 @@ def dqn_bench(a):
     t_td = _time_launches(lambda: lib.dqn_td_step(p(pk.P), p(pk.PF), p(pk.PT), p(pk.P_tgt), p(pk.PF_tgt), p(rp.obs[0]),
                                                   p(rp.next_obs[0]), p(rp.action[0]), p(rp.reward[0]), p(rp.done[0]), n,
                                                   C.c_float(0.99), C.c_float(1.0 / (n * mb)), p(agent._h1), p(agent._h2),
-                                                  p(agent._dz3), p(agent._dz2), p(agent._dz1), p(agent._loss_part), st),
+                                                  p(agent._dz3), p(agent._dz2), p(agent._dz1), p(agent._loss_part[0]), st),
                           a.kernel_reps)
     t_gw = _time_launches(lambda: lib.dqn_grad_w(p(rp.obs[0]), p(agent._h1), p(agent._h2), p(agent._dz1), p(agent._dz2),
                                                  p(agent._dz3), n, p(agent._gw_ws), p(pk.G), 1, st), a.kernel_reps)

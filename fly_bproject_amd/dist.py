@@ -54,6 +54,7 @@ class P2PAllReduce:
         from . import _lib
         self._C, self._lib, self._libmod = C, _lib.load(), _lib
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self._group = group
         self.n = int(n_floats)
         if self.n % 4 or self.world > 16:
             raise ValueError("P2PAllReduce: n_floats must be a multiple of 4 and world <= 16")
@@ -97,11 +98,14 @@ class P2PAllReduce:
         return bad == 0
 
     def close(self):
+        """Collective: every rank closes the windows it opened, THEN (behind a barrier) frees its own."""
         if self._mine:
             torch.cuda.synchronize(self.device)
             for ptr in self._opened:
                 self._lib.dp_ipc_close(ptr)
             self._opened = []
+            if dist.is_initialized():
+                dist.barrier(group=self._group)
             self._lib.dp_p2p_free(self._mine)
             self._mine = self._C.c_void_p()
 

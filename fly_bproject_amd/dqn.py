@@ -228,8 +228,8 @@ class DQN:
         self._ws_rows = r
         self._h1, self._h2, self._dz1, self._dz2, self._dz3 = e(H), e(H), e(H), e(H), e(OUT)
         self._gw_ws = torch.empty(int(self._lib.dqn_grad_workspace_floats()), device=dev)
-        self._loss_part = torch.zeros(r // 32, device=dev)
-        self._loss_acc = torch.zeros((), device=dev)
+        # per-tile Huber sums of every sampled step of one update (summed ONCE at its end, not per step)
+        self._loss_part = torch.zeros(max(1, int(getattr(self, "mini_batch_size", 1))), r // 32, device=dev)
 
     def update(self, chunks=None):
         """dqn.py:64-85.  `chunks` (tests) = a list of `(obs, act, reward, next_obs, done_mask)` row blocks that
@@ -241,25 +241,25 @@ class DQN:
         st = _lib.stream_ptr()
         B = sum(int(c[0].shape[0]) for c in chunks)
         inv_B = 1.0 / float(B)
-        self._loss_acc.zero_()
+        if len(chunks) > self._loss_part.shape[0] or max(int(c[0].shape[0]) for c in chunks) > self._ws_rows:
+            self.mini_batch_size = max(self.mini_batch_size, len(chunks))
+            self._alloc_workspace(max(int(c[0].shape[0]) for c in chunks))
+        self._loss_part.zero_()
         for i, (obs, act, reward, next_obs, done_mask) in enumerate(chunks):
             n = int(obs.shape[0])
-            if n > self._ws_rows:
-                self._alloc_workspace(n)
             for t in (obs, act, reward, next_obs, done_mask):
                 assert t.is_contiguous() and t.dtype == torch.float32
             _lib.check(lib.dqn_td_step(p(pk.P), p(pk.PF), p(pk.PT), p(pk.P_tgt), p(pk.PF_tgt), p(obs), p(next_obs), p(act),
                                        p(reward), p(done_mask), C.c_int64(n), C.c_float(self.discount), C.c_float(inv_B),
-                                       p(self._h1), p(self._h2), p(self._dz3), p(self._dz2), p(self._dz1), p(self._loss_part),
+                                       p(self._h1), p(self._h2), p(self._dz3), p(self._dz2), p(self._dz1), p(self._loss_part[i]),
                                        st), "dqn_td_step")
             _lib.check(lib.dqn_grad_w(p(obs), p(self._h1), p(self._h2), p(self._dz1), p(self._dz2), p(self._dz3), C.c_int64(n),
                                       p(self._gw_ws), p(pk.G), C.c_int(1 if i else 0), st), "dqn_grad_w")
-            self._loss_acc += self._loss_part[: (n + 31) // 32].sum()
         _lib.check(lib.dqn_adam_soft_update(p(pk.P), p(pk.PF), p(pk.PT), p(pk.P_tgt), p(pk.PF_tgt), p(pk.idx_f), p(pk.idx_t),
                                             p(pk.G), p(pk.grad_mask), p(pk.exp_avg), p(pk.exp_avg_sq), p(pk.step),
                                             C.c_float(self.lr), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8),
                                             C.c_float(self.tau), st), "dqn_adam_soft_update")
-        return self._loss_acc * inv_B                                     # F.smooth_l1_loss: mean over the batch
+        return self._loss_part.sum() * inv_B                              # F.smooth_l1_loss: mean over the batch
 
     def q_parameters(self):
         return list(self.q.parameters())
