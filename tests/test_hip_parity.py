@@ -476,3 +476,76 @@ def test_advantage_normalisation(lib, n):
     want = (a.astype(np.float64) - a.astype(np.float64).mean()) / (a.astype(np.float64).std(ddof=1) + 1e-8)
     np.testing.assert_allclose(da.cpu().numpy(), want, rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(float(stats[0]), a.astype(np.float64).sum(), rtol=1e-4, atol=1e-2)
+
+
+def test_integrator_against_closed_form_recurrences():
+    """FlyDyn has no reference oracle (PhysX is a closed binary), and the C oracle is the build's own.  This test
+    holds the HIP integrator to the SPECIFICATION equations (oracle/fly_physics.inc header) directly, on cases whose
+    discrete recurrence can be written down in float64 without any shared code:
+      * contact-free flight: v <- (v + h g) (1 - h lin_damp); z <- z + h v; x/y drift with damped velocity;
+      * torque-free spin about a principal body axis: w_b <- w_b (1 - h ang_damp), and the quaternion advances by
+        the first-order update q <- normalise(q + h/2 (w,0) (x) q) -- compared through the rotation ANGLE about that axis;
+      * the PD position drive of a free joint (leg in the air): tau = clamp(kp (tgt - q) - kd qd, effort),
+        qd <- clamp(qd + h tau / J, vmax), q <- q + h qd, clamped at the joint limits."""
+    n = 64
+    for variant in ("bigGrav", "lowGrav"):
+        cfg = O.default_config(n, variant)
+        env = make_env(n, variant)
+        rng = np.random.default_rng(3)
+        s = O.EnvState(n)
+        pose = np.array(cfg.dof_pose[:], np.float64)
+        lo, hi = np.array(cfg.dof_lo[:], np.float64), np.array(cfg.dof_hi[:], np.float64)
+        s.root[:] = 0
+        s.root[:, 2] = 5000.0                                  # far above the plane: no contact during the test
+        s.root[:, 6] = 1.0
+        s.root[:, 7:10] = rng.normal(0, 3, (n, 3))
+        axis = rng.integers(0, 3, n)                            # spin about body x, y or z (identity orientation: body = world)
+        w0 = rng.uniform(-5, 5, n)
+        s.root[np.arange(n), 10 + axis] = w0
+        s.dof_pos[:] = np.clip(pose + rng.normal(0, 0.3, (n, 18)), lo, hi)
+        s.dof_vel[:] = rng.normal(0, 0.2, (n, 18))
+        tgt = np.clip(pose + rng.normal(0, 0.5, (n, 18)), lo, hi).astype(np.float32)
+        s.targets[:] = tgt
+        s.reset[:] = 0
+        push_state(env, s)
+        steps = 3
+        for _ in range(steps):
+            env.simulate()
+        got = pull_state(env)
+        h = float(cfg.dt) / cfg.substeps
+        ld, ad = 1.0 - h * float(cfg.lin_damp), 1.0 - h * float(cfg.ang_damp)
+        g = float(cfg.gravity)
+        pos = s.root[:, :3].astype(np.float64).copy(); vel = s.root[:, 7:10].astype(np.float64).copy()
+        w = w0.astype(np.float64).copy(); ang = np.zeros(n)
+        q = s.dof_pos.astype(np.float64).copy(); qd = s.dof_vel.astype(np.float64).copy()
+        kp, kd, eff, vmax, J = float(cfg.kp), float(cfg.kd), float(cfg.effort), float(cfg.vmax), float(cfg.joint_inertia)
+        for _ in range(steps * cfg.substeps):
+            tau = np.clip(kp * (tgt.astype(np.float64) - q) - kd * qd, -eff, eff)
+            qd = np.clip(qd + h * tau / J, -vmax, vmax)
+            q = q + h * qd
+            below, above = q < lo, q > hi
+            qd = np.where(below, np.maximum(qd, 0), np.where(above, np.minimum(qd, 0), qd))
+            q = np.clip(q, lo, hi)
+            vel = vel + h * np.array([0.0, 0.0, g])
+            vel = np.clip(vel * ld, -float(cfg.max_lin_vel), float(cfg.max_lin_vel))
+            pos = pos + h * vel
+            w = np.clip(w * ad, -float(cfg.max_ang_vel), float(cfg.max_ang_vel))
+            # first-order quaternion update about a fixed axis: (cos a, sin a) <- normalise((cos a, sin a) + h/2 w (-sin a, cos a))
+            half = ang / 2
+            c, sn = np.cos(half) - 0.5 * h * w * np.sin(half), np.sin(half) + 0.5 * h * w * np.cos(half)
+            ang = 2 * np.arctan2(sn, c)
+        scale = np.maximum(1.0, np.abs(pos))
+        assert np.max(np.abs(got.root[:, :3] - pos) / scale) < 2e-6, variant          # fp32 rounding of |z| = 5000
+        np.testing.assert_allclose(got.root[:, 7:10], vel, rtol=2e-5, atol=2e-4)
+        np.testing.assert_allclose(got.root[np.arange(n), 10 + axis], w, rtol=2e-5, atol=1e-5)
+        off = np.array([[1, 2], [0, 2], [0, 1]])[axis]                                # the other two components stay 0
+        assert np.abs(got.root[np.arange(n)[:, None], 10 + off]).max() < 1e-5
+        got_ang = 2 * np.arctan2(got.root[np.arange(n), 3 + axis].astype(np.float64), got.root[:, 6].astype(np.float64))
+        d = np.abs((got_ang - ang + np.pi) % (2 * np.pi) - np.pi)
+        assert d.max() < 2e-5, (variant, d.max())
+        np.testing.assert_allclose(got.dof_pos, q, rtol=2e-5, atol=2e-5)
+        # the stiff drive (kp h / J ~ 80 per substep) amplifies fp32 rounding of q in the unsaturated band: the suite's
+        # velocity tolerance
+        np.testing.assert_allclose(got.dof_vel, qd, rtol=5e-3, atol=5e-3)
+        assert np.all(got.contact == 0)
+        env.exit()
