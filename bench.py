@@ -381,7 +381,7 @@ def dqn_bench(a):
                                                   p(agent._dz3), p(agent._dz2), p(agent._dz1), p(agent._loss_part[0]), st),
                           a.kernel_reps)
     t_gw = _time_launches(lambda: lib.dqn_grad_w(p(rp.obs[0]), p(agent._h1), p(agent._h2), p(agent._dz1), p(agent._dz2),
-                                                 p(agent._dz3), n, p(agent._gw_ws), p(pk.G), 1, st), a.kernel_reps)
+                                                 p(agent._dz3), n, p(agent._gw_ws), p(pk.G), 1, st), a.kernel_reps)      # a middle step of a batch: no reduction
     t_act = _time_launches(lambda: lib.dqn_act(p(pk.P), p(pk.PF), p(rp.obs[0]), n, p(agent._coin), p(agent._rand),
                                                C.c_float(0.1), p(agent._dz3), None, st), a.kernel_reps)
 
@@ -392,7 +392,7 @@ def dqn_bench(a):
                 "algorithmic_per_launch": flop, "launches_per_step": per_step, "step_share_ms": round(dur * per_step * 1e3, 3)}
     ks = [mfma("dqn_td_kernel (target fwd + online fwd + Huber-TD + dX chain, %d rows)" % n, t_td,
                (2 * DQN_FWD_FLOP + DQN_BWD_DX_FLOP) * n, mb),
-          mfma("dqn_grad_w_kernel (+reduce)", t_gw, DQN_FWD_FLOP * n, mb),
+          mfma("dqn_grad_w_kernel (partials accumulate; one reduction per update)", t_gw, DQN_FWD_FLOP * n, mb),
           mfma("dqn_act_kernel (forward + argmax + eps-greedy)", t_act, DQN_FWD_FLOP * n, 1)]
     agent.exit()
     print(json.dumps({

@@ -8,7 +8,8 @@
 //                                       forward of next_obs -> max_a, online forward of obs (h1/h2 saved),
 //                                       TD target, Huber loss, d loss / d Q, and the dX chain down to dZ1
 //   dqn_grad_w_kernel   loss.backward() dW / db of the three layers over row slabs (grad_w_layer.inc)
-//   dqn_grad_reduce_kernel              fixed-order sum of the partial slabs; accumulates over the sampled steps
+//   dqn_grad_reduce_kernel              fixed-order sum of the partial slabs, ONCE per update (the slabs themselves
+//                                       accumulate over the update's sampled steps)
 //   dqn_adam_kernel     dqn.py:81-84    Adam (3e-4, torch defaults, NO clipping) on the packed parameters, refresh of
 //                                       the fragment-ordered copies, and the soft update of the target network
 //                                       (target = target*tau + param*(1-tau)) with its fragment copy
@@ -423,6 +424,8 @@ extern "C" int64_t flyhip_dqn_grad_workspace_floats(void)
            (int64_t)kDqnGradWgs[2] * DQN_OUT * (DQN_H + 1);
 }
 
+// accumulate: bit 0 = add this step's dW to the partial slabs (steps 2.. of an update), bit 1 = this is the LAST step:
+// reduce the slabs into `grad` now (one reduction per update, not per sampled step)
 extern "C" hipError_t flyhip_launch_dqn_grad_w(const float* x, const float* h1, const float* h2, const float* dz1,
                                                const float* dz2, const float* dz3, int64_t n, float* workspace, float* grad,
                                                int accumulate, void* stream)
@@ -438,6 +441,7 @@ extern "C" hipError_t flyhip_launch_dqn_grad_w(const float* x, const float* h1, 
     for (int l = 0; l < 3; ++l) {
         T.l[l].dz = dz[l]; T.l[l].a = a[l]; T.l[l].partial = ws;
         T.l[l].N = N[l]; T.l[l].Ka = Ka[l]; T.l[l].KP = KP[l]; T.l[l].wgs = kDqnGradWgs[l]; T.l[l].first_block = first;
+        T.l[l].accumulate = accumulate & 1;
         ws += (long)kDqnGradWgs[l] * ((long)N[l] * KP[l] + N[l]);
         first += kDqnGradWgs[l];
     }
@@ -453,9 +457,8 @@ extern "C" hipError_t flyhip_launch_dqn_grad_w(const float* x, const float* h1, 
     }
     hipLaunchKernelGGL(dqn_grad_w_kernel, dim3(first), dim3(GW_THREADS), lds_bytes, (hipStream_t)stream, T, (long)n);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dqn_grad_reduce_kernel, dim3(DQ_RED_BLOCKS), dim3(64 * DQ_RED_WAVES), 0, (hipStream_t)stream, T, grad,
-                       accumulate);
+    if (e != hipSuccess || !(accumulate & 2)) return e;
+    hipLaunchKernelGGL(dqn_grad_reduce_kernel, dim3(DQ_RED_BLOCKS), dim3(64 * DQ_RED_WAVES), 0, (hipStream_t)stream, T, grad, 0);
     return hipGetLastError();
 }
 

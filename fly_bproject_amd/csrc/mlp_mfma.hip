@@ -259,6 +259,7 @@ extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, 
     for (int l = 0; l < 4; ++l) {
         T.l[l].dz = dz[l]; T.l[l].a = a[l]; T.l[l].partial = ws;
         T.l[l].N = N[l]; T.l[l].Ka = Ka[l]; T.l[l].KP = KP[l]; T.l[l].wgs = wgs[l]; T.l[l].first_block = first;
+        T.l[l].accumulate = 0;
         ws += (long)wgs[l] * ((long)N[l] * KP[l] + N[l]);
         first += wgs[l];
     }

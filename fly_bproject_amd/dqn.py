@@ -254,7 +254,8 @@ class DQN:
                                        p(self._h1), p(self._h2), p(self._dz3), p(self._dz2), p(self._dz1), p(self._loss_part[i]),
                                        st), "dqn_td_step")
             _lib.check(lib.dqn_grad_w(p(obs), p(self._h1), p(self._h2), p(self._dz1), p(self._dz2), p(self._dz3), C.c_int64(n),
-                                      p(self._gw_ws), p(pk.G), C.c_int(1 if i else 0), st), "dqn_grad_w")
+                                      p(self._gw_ws), p(pk.G), C.c_int((1 if i else 0) | (2 if i == len(chunks) - 1 else 0)), st),
+                       "dqn_grad_w")
         _lib.check(lib.dqn_adam_soft_update(p(pk.P), p(pk.PF), p(pk.PT), p(pk.P_tgt), p(pk.PF_tgt), p(pk.idx_f), p(pk.idx_t),
                                             p(pk.G), p(pk.grad_mask), p(pk.exp_avg), p(pk.exp_avg_sq), p(pk.step),
                                             C.c_float(self.lr), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8),

@@ -363,9 +363,11 @@ int dqn_huber_td(const float* q_table, const float* act, const float* reward, co
  *                   gradient at the Q table scaled by inv_B (1 / rows of the WHOLE batch), and the backward
  *                   chain down to the first layer's pre-activations.  Leaves h1, h2, dz1, dz2 f32 [n32][256]
  *                   and dz3 f32 [n32][32] (n32 = n rounded up to 32; tile-fragment order) for dqn_grad_w.
- *   dqn_grad_w    : dW / db of the three layers from those tensors into `grad` (packed layout);
- *                   accumulate != 0 adds to `grad` (one call per sampled step of a batch).  `workspace`
- *                   holds dqn_grad_workspace_floats() floats.
+ *   dqn_grad_w    : dW / db of the three layers from those tensors.  One call per sampled step of a batch:
+ *                   accumulate bit 0 = add to the partial slabs in `workspace` (every step but the first),
+ *                   bit 1 = last step: reduce the slabs into `grad` (packed layout) now.  A single-step batch
+ *                   passes 2.  `workspace` holds dqn_grad_workspace_floats() floats and must not be touched
+ *                   between the calls of one batch.
  *   dqn_adam_soft_update : dqn.py:81-84: Adam (torch defaults, no clipping) on `params` with the refresh
  *                   of its fragment copies, then target = target * tau + params * (1 - tau)
  *                   (dqn.py:33-36) with the target's forward fragment copy.  `mask` (packed, 0/1) freezes
