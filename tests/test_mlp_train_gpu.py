@@ -215,9 +215,45 @@ def test_one_launch_forward_backward_equals_two_launches(n):
     assert int(pol.tile_wait_error.item()) == 0 and pol._epoch == e0 + 2
 
 
+@pytest.mark.parametrize("n", [4099, 40960])
+def test_grad_w_kernels_against_fp64(n):
+    """dW = dZ^T A of both arithmetics (fp32 MFMA chain; bf16x3 on the bf16 pipe, six terms into ONE fp32 accumulator
+    per tile) against an fp64 evaluation on the same saved tensors: the bf16x3 kernel's error must stay within 2x of the
+    fp32 kernel's (its licence to replace it) and both inside the suite's gradient tolerance."""
+    from fly_bproject_amd.policy import untile
+    net, ref, pol, (x, action, old_logp, adv, target, var) = _setup(n, 31)
+    pol.gemm = "f32"
+    pol.minibatch_grad(x, action, old_logp, adv, target, var, 0.2)
+    torch.cuda.synchronize()
+    g = {"f32": pol.G.clone()}
+    width = {"h1": 256, "h2": 128, "h3": 128, "dz4": 32, "dz3": 128, "dz2": 128, "dz1": 256}
+    a = [x.double()] + [untile(pol.saves[k], n, width[k]).double() for k in ("h1", "h2", "h3")]
+    dz = [untile(pol.dz[k], n, width[k]).double() for k in ("dz1", "dz2", "dz3", "dz4")]
+    # the same saved tensors through the bf16x3 dW kernel alone
+    import ctypes as C
+    from fly_bproject_amd import _lib
+    p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    s_, d_ = pol.saves, pol.dz
+    _lib.check(_lib.load().mlp_grad_w(p(x), p(s_["h1"]), p(s_["h2"]), p(s_["h3"]), p(d_["dz1"]), p(d_["dz2"]), p(d_["dz3"]), p(d_["dz4"]),
+                                      C.c_int64(n), p(pol.workspace), p(pol.G), None, None, None, None, 1, None), "mlp_grad_w b3")
+    torch.cuda.synchronize()
+    g["bf16x3"] = pol.G.clone()
+    views = lambda G: [(G[:256 * 80].view(256, 80)[:, :73], G[20480:20736]), (G[20736:53504].view(128, 256), G[53504:53632]),   # noqa: E731
+                       (G[53632:70016].view(128, 128), G[70016:70144]), (G[70144:74240].view(32, 128), G[74240:74272])]
+    err = {}
+    for mode in g:
+        worst = 0.0
+        for (W, b), A, Z in zip(views(g[mode]), a, dz):
+            W64, b64 = Z.T @ A, Z.sum(0)
+            scale = float(W64.abs().max()) + 1e-30
+            worst = max(worst, float((W.double() - W64).abs().max()) / scale, float((b.double() - b64).abs().max()) / (float(b64.abs().max()) + 1e-30))
+        err[mode] = worst
+    assert err["f32"] <= 2e-5 and err["bf16x3"] <= 2e-5, err
+    assert err["bf16x3"] <= 2.0 * err["f32"] + 1e-7, err
+
+
 def test_bf16x3_training_step_matches_fp32_path():
-    """One minibatch gradient + Adam step with the bf16x3 GEMMs (forward, dX chain; dW stays on fp32
-    MFMA) against the fp32-MFMA path and torch autograd: same loss and gradients to the suite's fp32
+    """One minibatch gradient + Adam step with the bf16x3 GEMMs (forward, dX chain, dW) against the fp32-MFMA path and torch autograd: same loss and gradients to the suite's fp32
     tolerance, and the bf16 term planes the Adam kernel scatters equal a fresh split of the weights."""
     from fly_bproject_amd.policy import split_bf16x3, untile
     n = 4099
