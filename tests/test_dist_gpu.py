@@ -45,17 +45,20 @@ def _p2p_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_p2p_allreduce_two_ranks_one_gpu(tmp_path):
-    """dp_allreduce_p2p between two processes (both on cuda:0, windows exchanged through hipIpc): after every
-    epoch both ranks hold the sum of the two inputs, added in rank order, bit for bit -- 40 epochs back to back
+@pytest.mark.parametrize("world", [2, 4])
+def test_p2p_allreduce_ranks_on_one_gpu(tmp_path, world):
+    """dp_allreduce_p2p between `world` processes (all on cuda:0, windows exchanged through hipIpc): after every
+    epoch every rank holds the sum of all inputs, added in rank order, bit for bit -- 40 epochs back to back
     with uneven arrival.  (Exercises the protocol and the IPC plumbing; the xGMI leg needs a multi-GPU node.)"""
     port = _free_port()
-    mp.spawn(_p2p_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    a = torch.load(tmp_path / "p2p0.pt", weights_only=True)
-    b = torch.load(tmp_path / "p2p1.pt", weights_only=True)
-    for (mine0, out0), (mine1, out1) in zip(a, b):
-        want = (torch.zeros_like(mine0) + mine0) + mine1    # rank order, starting from 0
-        assert torch.equal(out0, want) and torch.equal(out1, want)
+    mp.spawn(_p2p_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(tmp_path / ("p2p%d.pt" % r), weights_only=True) for r in range(world)]
+    for it in range(len(outs[0])):
+        want = torch.zeros_like(outs[0][it][0])
+        for r in range(world):
+            want = want + outs[r][it][0]                    # rank order, starting from 0
+        for r in range(world):
+            assert torch.equal(outs[r][it][1], want), (it, r)
 
 
 def _worker(rank, world, port, out_dir, dp_mode="grad_allreduce"):
