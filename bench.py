@@ -456,6 +456,19 @@ def main():
     iteration()
     fence()
     rollout_s = time.perf_counter() - r0
+    # labelled variant: the same rollout as ONE launch (ppo_rollout_all, opt-in `persistent_rollout`: the device then runs
+    # ahead of the host's step count inside a rollout, so it is not the default of the drop-in `run()`)
+    persist_s = None
+    try:
+        agent.persistent_rollout = True
+        iteration()
+        fence()
+        p0 = time.perf_counter()
+        iteration()
+        fence()
+        persist_s = time.perf_counter() - p0
+    finally:
+        agent.persistent_rollout = False
     agent.args.testing = False
     if world > 1:
         tt = torch.tensor([elapsed, rollout_s], device=dev, dtype=torch.float64)
@@ -514,6 +527,7 @@ def main():
                        "grad_exchange": "none (1 rank)" if world == 1 else
                        ("%s, one call per optimizer step (75 per iteration), 297 KB" % agent_exchange)},
             "rollout_only_env_steps_per_s": round(world * a.num_envs * T / rollout_s, 1),
+            "rollout_only_one_launch_per_rollout_env_steps_per_s": None if not persist_s else round(world * a.num_envs * T / persist_s, 1),
             "params_finite": finite,
             "mean_episode_return": None if ep_cnt == 0 else round(ep_ret, 4),
             "mean_episode_length": None if ep_cnt == 0 else round(ep_len, 2), "episodes_finished": ep_cnt,

@@ -82,6 +82,11 @@ extern "C" hipError_t flyhip_launch_mlp_fwd_bwd(const float* P, const float* PF,
                                                 float* dz4, float* dz3, float* dz2, float* dz1, float* loss_part,
                                                 int* flags, int epoch, int* err, const uint16_t* PB, const uint16_t* PTB,
                                                 int coherent, void* stream);
+extern "C" hipError_t flyhip_launch_rollout_all(const FlyConfig* dcfg, const FlyBuffers* b, const float* P, const float* PF,
+                                                float* obs_ring, int64_t n, const float* eps_all, const float* var,
+                                                float var_decay, float var_min, float* act_all, float* logp_all, float* v_ring,
+                                                float* reward_all, int T, const int* rows_applied, const uint16_t* PB,
+                                                void* stream);
 extern "C" hipError_t flyhip_launch_rollout_bookkeeping(const float* reward, int64_t rows, int64_t n, float* terms,
                                                         float* score_acc, float score_scale, float* action_var, int nvar,
                                                         float var_decay, float var_min, int* rows_applied, void* stream);
@@ -207,6 +212,26 @@ int ppo_rollout_step(FlyHandle h, const FlyBuffers* b, const float* params, cons
     hipError_t e = flyhip_launch_rollout_step(h->dev, b, params, params_frag, x, h->host.num_envs, eps, var, var_steps,
                                               var_decay, var_min, act_out, logp_out, v_out, params_b3, var_steps_base, stream);
     if (e != hipSuccess) return hip_fail(e, "ppo_rollout_step launch");
+    return FLY_OK;
+}
+
+int ppo_rollout_all(FlyHandle h, const FlyBuffers* b, const float* params, const float* params_frag, float* obs_ring,
+                    const float* eps_all, const float* var, float var_decay, float var_min, float* act_all,
+                    float* logp_all, float* v_ring, float* reward_all, int32_t T, const int32_t* rows_applied,
+                    const uint16_t* params_b3, void* stream)
+{
+    if (!h) return fail(FLY_E_ARG, "handle is null");
+    if (!params || !params_frag || !obs_ring || !eps_all || !var || !act_all || !logp_all || !v_ring || !reward_all)
+        return fail(FLY_E_ARG, "ppo_rollout_all: null pointer");
+    if (T <= 0 || T > (1 << 20)) return fail(FLY_E_ARG, "ppo_rollout_all: T out of range");
+    FlyBuffers bb = *b;
+    bb.obs = obs_ring; bb.reward = reward_all;              // checked as present; the kernel walks the rows itself
+    int rc = check_buffers(&bb, PH_SCALE | PH_RESET | PH_INTEGRATE | PH_OBS | PH_PROGRESS | PH_REWARD);
+    if (rc) return rc;
+    hipError_t e = flyhip_launch_rollout_all(h->dev, &bb, params, params_frag, obs_ring, h->host.num_envs, eps_all, var,
+                                             var_decay, var_min, act_all, logp_all, v_ring, reward_all, T, rows_applied,
+                                             params_b3, stream);
+    if (e != hipSuccess) return hip_fail(e, "ppo_rollout_all launch");
     return FLY_OK;
 }
 

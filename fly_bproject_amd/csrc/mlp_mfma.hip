@@ -70,7 +70,83 @@ __global__ __launch_bounds__(THREADS, B3 ? 1 : 2) void rollout_step_kernel(
     fly_body<PH_ALL>(c, act, b, lds, blockIdx.x, st);
 }
 
+// One launch per ROLLOUT (ppo.py:204-237 for T consecutive env steps): the envs of a 32-env tile depend on no other
+// tile and the policy does not change inside a rollout, so workgroup b simply loops over the T steps of ITS tile --
+// policy forward + sampling on observation row t, env step, observation row t + 1 -- with the env state carried in
+// registers.  What a launch per step pays T times (the launch boundary, the prologue, the state's round trip) is paid
+// once.  Row t's buffers are row t of the rollout tensors (fixed strides); the deferred bookkeeping is exact because
+// row t decays the variance t - *rows_applied times and no flush can run while the launch does.  Between steps the
+// workgroup waits for its own observation-row stores (vmcnt(0) + barrier): row t + 1 is read only by the workgroup
+// that wrote it, at addresses this CU has not read before.  Bit for bit what T launches of rollout_step_kernel leave.
+// WPS = waves per SIMD the registers are budgeted for: 1 when the launch has at most one workgroup per CU (<= 8192
+// envs: the step body plus the carried env state want ~300 registers and spill at 256), 2 beyond that.
+template <bool B3, int WPS>
+__global__ __launch_bounds__(THREADS, WPS) void rollout_all_kernel(
+    const FlyConfig* __restrict__ c, FlyBuffers b, const float* __restrict__ P, const void* __restrict__ PF,
+    float* __restrict__ obs_ring, long n, const float* __restrict__ eps_all, const float* __restrict__ var, float var_decay,
+    float var_min, float* __restrict__ act_all, float* __restrict__ logp_all, float* __restrict__ v_ring,
+    float* __restrict__ reward_all, int T, const int* __restrict__ rows_applied)
+{
+    constexpr int ARENA = B3 ? RS_B3_LDS_FLOATS : RS_LDS_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[ARENA + 32];
+    constexpr int PH_ALL = PH_SCALE | PH_RESET | PH_INTEGRATE | PH_OBS | PH_PROGRESS | PH_REWARD;
+    // the variance of the CURRENT row lives in LDS and is decayed once per step (ppo.py:236-237): the same sequence of
+    // fp32 operations as the per-step form, O(1) per step however long the rollout (T = 40 960 at 16 envs)
+    float* varcur = lds + ARENA;
+    if (threadIdx.x < MLP_NACT) {
+        float v = var[threadIdx.x];
+        const int pending = rows_applied ? -*rows_applied : 0;         // rows of this rollout not yet applied to `var` (0 at its start)
+        for (int i = 0; i < pending; ++i) v = fmaxf(var_min, v - var_decay);
+        varcur[threadIdx.x] = v;
+    }
+    FlyRegs st;
+    fly_load<PH_ALL>(st, c, b, blockIdx.x);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const float* x = obs_ring + (long)t * n * FLY_NUM_OBS;
+        float* act = act_all + (long)t * n * MLP_NACT;
+        b.obs = obs_ring + (long)(t + 1) * n * FLY_NUM_OBS;
+        b.reward = reward_all + (long)t * n;
+        if (B3)
+            forward_body_b3<false>(lds, blockIdx.x, 1L << 40, P, static_cast<const u16*>(PF), x, n, nullptr, v_ring + (long)t * n,
+                                   nullptr, nullptr, nullptr, nullptr, eps_all + (long)t * n * MLP_NACT, varcur, act,
+                                   logp_all + (long)t * n, nullptr, 0, var_decay, var_min);
+        else
+            forward_body<false>(lds, blockIdx.x, 1L << 40, P, static_cast<const float*>(PF), x, n, nullptr, v_ring + (long)t * n,
+                                nullptr, nullptr, nullptr, nullptr, eps_all + (long)t * n * MLP_NACT, varcur, act,
+                                logp_all + (long)t * n, nullptr, 0, var_decay, var_min);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);          // this thread's action stores are acknowledged by L2
+        __syncthreads();
+        FlyRegs nx;
+        fly_body<PH_ALL>(c, act, b, lds, blockIdx.x, st, &nx);
+        st = nx;
+        if (threadIdx.x < MLP_NACT && var_decay > 0.0f) varcur[threadIdx.x] = fmaxf(var_min, varcur[threadIdx.x] - var_decay);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // observation row t + 1 is in L2 before any wave of this workgroup reads it
+        __syncthreads();
+    }
+}
+
 }  // namespace
+
+extern "C" hipError_t flyhip_launch_rollout_all(const FlyConfig* dcfg, const FlyBuffers* b, const float* P, const float* PF,
+                                                float* obs_ring, int64_t n, const float* eps_all, const float* var,
+                                                float var_decay, float var_min, float* act_all, float* logp_all, float* v_ring,
+                                                float* reward_all, int T, const int* rows_applied, const uint16_t* PB,
+                                                void* stream)
+{
+    const dim3 grid((unsigned)((n + BM - 1) / BM));
+    int cus = 256;
+    { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; }
+    const bool one_per_cu = (int)grid.x <= cus;
+#define RA_LAUNCH(B3_, WPS_, PF_)                                                                                                  \
+    hipLaunchKernelGGL((rollout_all_kernel<B3_, WPS_>), grid, dim3(THREADS), 0, (hipStream_t)stream, dcfg, *b, P, (const void*)PF_, \
+                       obs_ring, (long)n, eps_all, var, var_decay, var_min, act_all, logp_all, v_ring, reward_all, T, rows_applied)
+    if (PB) { if (one_per_cu) RA_LAUNCH(true, 1, PB); else RA_LAUNCH(true, 1, PB); }      // the bf16x3 body needs one wave per SIMD anyway
+    else { if (one_per_cu) RA_LAUNCH(false, 1, PF); else RA_LAUNCH(false, 2, PF); }
+#undef RA_LAUNCH
+    return hipGetLastError();
+}
 
 extern "C" hipError_t flyhip_launch_mlp_forward(const float* P, const float* PF, const float* x, int64_t n, float* mu_out,
                                                 float* v_out, float* out_save, float* h1_save, float* h2_save,

@@ -110,6 +110,9 @@ class PPO:
         self.normalize_advantage = bool(getattr(args, "normalize_advantage", False))
         self._adv_stats = torch.zeros(514, device=dev)
         self.use_graph = bool(getattr(args, "graph", False))
+        # one launch per ROLLOUT (ppo_rollout_all): each workgroup loops over the T steps of its own 32 envs.  Like
+        # graph=True the device then runs ahead of the host's step count inside a rollout.
+        self.persistent_rollout = bool(getattr(args, "persistent_rollout", False))
         self._graphs = {}
         self._fwd_args = None
         self._score_acc = torch.zeros((), device=dev)
@@ -449,6 +452,20 @@ class PPO:
         self._after_step(t)
         env.render_count += 1
 
+    def _launch_rollout(self):
+        """The device work of a WHOLE rollout in one launch (`ppo_rollout_all`): eps draw, then every workgroup runs
+        the T steps of its own 32 envs with the env state in registers.  Bit for bit what T `_launch_step` calls leave."""
+        P = C.c_void_p
+        pol, env, T = self.policy, self.env, self.rollout_size
+        self._eps_all.normal_(generator=self._gen)
+        self._rows_applied.zero_()
+        _lib.check(self._lib.ppo_rollout_all(
+            env._handle, C.byref(env._bufs), P(pol.P.data_ptr()), P(pol.PF.data_ptr()), P(self._obs_ring.data_ptr()),
+            P(self._eps_all.data_ptr()), P(self._action_var.data_ptr()), C.c_float(self._var_decay), self._var_min,
+            P(self.all_acts.data_ptr()), P(self.all_log_prob.data_ptr()), P(self._v_ring.data_ptr()),
+            P(self.all_reward.data_ptr()), C.c_int(T), P(self._rows_applied.data_ptr()), pol.infer_pb_ptr(),
+            _lib.stream_ptr()), "ppo_rollout_all")
+
     def _after_step(self, t):
         """Host-side state of a step that has been issued (launched or replayed): rows whose score / variance
         bookkeeping is pending (ppo.py:233, :236-237, applied by _flush_bookkeeping) and how many rows of
@@ -469,7 +486,14 @@ class PPO:
         if self._fwd_args is None or self._args_infer_gemm != self.policy.gemm_infer:
             self._prepare_step_args()                               # (re)built when the inference arithmetic changes
         with torch.no_grad():
-            if not self.use_graph or self.run_step < self.rollout_size:
+            if self.persistent_rollout:
+                if t == 0:
+                    self._launch_rollout()
+                self.env.obs_buf, self.env.reward_buf = self._obs_rows[t + 1], self._reward_rows[t]
+                self.env._bufs.obs, self.env._bufs.reward = self._buf_ptrs[t]
+                self._after_step(t)
+                self.env.render_count += 1
+            elif not self.use_graph or self.run_step < self.rollout_size:
                 self._launch_step(t)
             else:
                 # graph=True: the device work of a WHOLE rollout (eps draw + T one-launch env steps) is one

@@ -252,6 +252,19 @@ int ppo_rollout_step(FlyHandle h, const FlyBuffers* b, const float* params, cons
                      float var_decay, float var_min, float* act_out, float* logp_out, float* v_out,
                      const uint16_t* params_b3, const int32_t* var_steps_base, void* stream);
 
+/* T consecutive steps of the rollout (ppo.py:204-237) in ONE launch: ppo_rollout_step for t = 0 .. T-1 on row t of
+ * the rollout tensors -- obs_ring f32 [T+1][N][73] (row 0 = the first observation; row t+1 receives step t's),
+ * eps_all / act_all f32 [T][N][18], logp_all / v_ring f32 [T][N] (v_ring may be [T+1][N]), reward_all f32 [T][N] --
+ * with the env state carried in registers from step to step (`b` gives the state tensors; its obs / reward members
+ * are ignored).  Envs of a 32-env tile depend on no other tile and the policy is constant inside a rollout, so each
+ * workgroup runs its own tile's T steps.  Row t decays the variance (t - *rows_applied) times (rows_applied optional).
+ * Bit for bit what T calls of ppo_rollout_step leave.  The launch runs for T x (one step's time): keep T <= a few
+ * thousand. */
+int ppo_rollout_all(FlyHandle h, const FlyBuffers* b, const float* params, const float* params_frag, float* obs_ring,
+                    const float* eps_all, const float* var, float var_decay, float var_min, float* act_all,
+                    float* logp_all, float* v_ring, float* reward_all, int32_t T, const int32_t* rows_applied,
+                    const uint16_t* params_b3, void* stream);
+
 
 /*
  * One PPO minibatch backward (ppo.py:184-197), three launches on the saved activations of

@@ -137,21 +137,21 @@ def test_rollout_values_equal_the_critic_pass():
 
 
 def test_graph_replay_matches_eager_rollout():
-    """graph=True replays the device work of a whole rollout from ONE captured hipGraph (the captured normal_
+    """graph=True (and persistent_rollout=True: one launch per rollout) replays the device work of a whole rollout from ONE captured hipGraph (the captured normal_
     advances the Philox offset like the eager call).  After whole rollouts everything equals the eager run bit for
     bit -- also when the score print's mid-rollout bookkeeping flush falls inside a replayed rollout (run_step 200,
     300 below).  Mid-rollout the DEVICE is ahead of the host's step count (documented in PPO.run): the rows the
     host has stepped through are final, env.reset_buf / progress_buf already hold the rollout's end state."""
     from fly_bproject_amd.ppo import PPO
     res = {}
-    for graph in (False, True):
+    for graph in (False, True, "persistent"):
         torch.manual_seed(0)
         with contextlib.redirect_stdout(io.StringIO()):
-            agent = PPO(make_args(4096, graph=graph, testing=True))
+            agent = PPO(make_args(4096, graph=graph is True, persistent_rollout=graph == "persistent", testing=True))
             T = agent.rollout_size
             _run(agent, 3 * T)                           # rollout 1 eager, rollout 2 captures + replays, rollout 3 replays
         torch.cuda.synchronize()
-        if graph:
+        if graph is True:
             assert len(agent._graphs) == 1
         res[graph] = (agent._obs_ring.clone(), agent.all_acts.clone(), agent.all_reward.clone(),
                       agent.all_log_prob.clone(), agent.env.progress_buf.clone(), float(agent.action_var[0]), agent._score_acc.clone())
@@ -162,11 +162,12 @@ def test_graph_replay_matches_eager_rollout():
         res[graph] += (agent.all_acts[:7].clone(), agent.all_log_prob[:7].clone(), agent._obs_ring[:8].clone(),
                        float(agent.action_var[0]), agent.env.obs_buf.clone())
         agent.exit()
-    for i, (a, b) in enumerate(zip(res[False], res[True])):
-        if torch.is_tensor(a):
-            assert torch.equal(a, b), i
-        else:
-            assert a == b, i
+    for mode in (True, "persistent"):       # "persistent": ONE launch per rollout (ppo_rollout_all), env state in registers
+        for i, (a, b) in enumerate(zip(res[False], res[mode])):
+            if torch.is_tensor(a):
+                assert torch.equal(a, b), (mode, i)
+            else:
+                assert a == b, (mode, i)
 
 
 @pytest.mark.parametrize("n", [33, 8192])

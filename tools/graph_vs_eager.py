@@ -17,10 +17,10 @@ from fly_bproject_amd.ppo import PPO  # noqa: E402
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "both"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
-for graph in ([False, True] if mode == "both" else [mode == "graph"]):
+for graph in ([False, True, "persistent"] if mode == "both" else [{"graph": True, "eager": False}.get(mode, "persistent")]):
     torch.manual_seed(0)
     with contextlib.redirect_stdout(io.StringIO()):
-        agent = PPO(make_args(n, graph=graph, testing=True))
+        agent = PPO(make_args(n, graph=graph is True, persistent_rollout=graph == "persistent", testing=True))
         T = agent.rollout_size
         for _ in range(2 * T):                      # rollout 1 eager (captures happen in rollout 2 for graph=True)
             agent.run()
@@ -37,6 +37,6 @@ for graph in ([False, True] if mode == "both" else [mode == "graph"]):
         host = time.perf_counter() - t1
         torch.cuda.synchronize()
     print("%s  %d envs: %.2f us per env step (wall, 10 rollouts); host issue time %.2f us per step; launches per step: %s"
-          % ("graph" if graph else "eager", n, dt / (10 * T) * 1e6, host / T * 1e6,
-             "one graph replay per ROLLOUT (T rollout_step nodes)" if graph else "1 (rollout_step, bookkeeping deferred)"))
+          % ({True: "graph", False: "eager"}.get(graph, "one launch per rollout"), n, dt / (10 * T) * 1e6, host / T * 1e6,
+             {True: "one graph replay per ROLLOUT (T rollout_step nodes)", False: "1 (rollout_step, bookkeeping deferred)"}.get(graph, "1 / T (ppo_rollout_all)")))
     agent.exit()
