@@ -35,9 +35,18 @@ def parse():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_alt_gemm", action="store_true", help="skip the secondary bf16x3 measurement")
     ap.add_argument("--kernel_reps", type=int, default=200)
-    ap.add_argument("--dp_allreduce", choices=["auto", "rccl", "p2p"], default="auto",
-                    help="per-optimizer-step gradient exchange of N > 1 ranks: auto = the one-shot peer-to-peer kernel if its "
-                         "start-up self-test against RCCL passes on this node, else RCCL")
+    ap.add_argument("--dp_allreduce", choices=["auto", "rccl", "p2p"], default="rccl",
+                    help="per-optimizer-step gradient exchange of N > 1 ranks: rccl (default) = torch.distributed.all_reduce; "
+                         "p2p = the one-shot peer-to-peer kernel; auto = p2p if its start-up self-test against RCCL passes on "
+                         "this node, else RCCL.  With rccl the p2p kernel is still opened, self-tested and TIMED as a labelled "
+                         "variant (`grad_exchange`), it just does not carry `value` until it has run on an xGMI node")
+    ap.add_argument("--gemm", choices=["bf16x3", "f32"], default=os.environ.get("FLY_GEMM", "bf16x3"),
+                    help="arithmetic of every MLP GEMM of `value`: bf16x3 = fp32 operands split exactly into three bf16 terms, six "
+                         "product terms on the bf16 matrix pipe, fp32 accumulate (held to the reference's golden vectors at the "
+                         "fp32 tolerances: tests/test_mlp_train_gpu.py, tests/test_ppo_gpu.py); f32 = v_mfma_f32_32x32x2_f32.  The "
+                         "other one is measured too and reported as the labelled secondary figure")
+    ap.add_argument("--no_dqn", action="store_true", help="skip the short labelled DQN block (configs[4]) of the default line")
+    ap.add_argument("--fail_rank", type=int, default=-1, help=argparse.SUPPRESS)     # test hook: that rank exits 3 at start
     ap.add_argument("--workload", choices=["ppo", "dqn"], default="ppo",
                     help="ppo (default, BASELINE's metric config) or dqn = BASELINE configs[4] (labelled line of its own)")
     ap.add_argument("--dqn_envs", type=int, default=32768)
@@ -51,25 +60,81 @@ def parse():
 def spawn_ranks(a):
     """`bench.py --gpus N` without an external launcher: start N rank processes (one per GPU) BEFORE this
     process touches the GPU, hand each the torch.distributed.run environment (RANK / LOCAL_RANK /
-    WORLD_SIZE / MASTER_*), and wait.  Rank 0's stdout carries the one JSON line.  Children are plain
-    child processes (never an exec of a GPU-initialised parent)."""
+    WORLD_SIZE / MASTER_*), and watch ALL of them: the first rank that exits non-zero gets its siblings
+    terminated within seconds (they would otherwise sit in a collective until the outer time limit) and its exit
+    code returned; the stderr of every rank is kept (rank 0's goes through, the others' tails are printed on
+    failure).  Rank 0's stdout carries the one JSON line.  Children are fresh child processes -- never an exec of
+    a GPU-initialised parent."""
     import socket
     import subprocess
+    import tempfile
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    procs, logs = [], []
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        log = None if r == 0 else tempfile.TemporaryFile(mode="w+")
+        logs.append(log)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+                                      stdout=None if r == 0 else subprocess.DEVNULL, stderr=log))
+    rc, first_bad = 0, None
+    live = set(range(a.gpus))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and first_bad is None:
+                first_bad, rc = r, (abs(code) or 1)
+        if first_bad is not None and live:
+            for r in live:
+                procs[r].terminate()
+            deadline = time.time() + 10
+            for r in sorted(live):
+                try:
+                    procs[r].wait(timeout=max(0.1, deadline - time.time()))
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+                    procs[r].wait()
+            live.clear()
+        if live:
+            time.sleep(0.2)
+    if first_bad is not None:
+        sys.stderr.write("bench.py: rank %d exited with code %d; the other ranks were terminated\n" % (first_bad, rc))
+        for r, log in enumerate(logs):
+            if log is not None:
+                log.seek(0)
+                tail = log.read()[-2000:]
+                if tail.strip():
+                    sys.stderr.write("---- stderr of rank %d (tail) ----\n%s\n" % (r, tail))
     return rc
+
+
+def device_identity(rank, local_rank, cuda=True):
+    """What the JSON line needs to show that N DISTINCT GPUs took part: per rank the device index, name, uuid and PCI
+    address as the runtime reports them."""
+    d = {"rank": rank, "local_rank": local_rank, "pid": os.getpid()}
+    if cuda:
+        pr = torch.cuda.get_device_properties(local_rank)
+        d.update(device_index=local_rank, name=pr.name, uuid=str(getattr(pr, "uuid", "")),
+                 pci="%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
+                 gcn_arch=getattr(pr, "gcnArchName", ""), cus=pr.multi_processor_count)
+    else:
+        d.update(device_index=None, name="cpu (dry run)")
+    return d
+
+
+def gather_identities(me, world):
+    if world == 1:
+        return [me]
+    out = [None] * world
+    dist.all_gather_object(out, me)
+    return out
 
 
 def make_args(n, **kw):
@@ -111,7 +176,7 @@ MLP_GRAD_W_FLOP = MLP_FWD_FLOP
 PEAK_HBM_GBS, PEAK_F32_MFMA_TFLOPS, PEAK_BF16_MFMA_TFLOPS = 8000.0, 157.3, 2500.0                             # MI355X_MICROARCH.md
 
 
-def kernel_rooflines(num_envs, T, reps):
+def kernel_rooflines(num_envs, T, reps, gemm="f32"):
     """Per-kernel roofline entries, each measured live with HIP events; the dominant kernel (largest
     share of one PPO iteration) is returned first."""
     import ctypes as C
@@ -127,6 +192,7 @@ def kernel_rooflines(num_envs, T, reps):
     net = Net(73, 18).to("cuda:0")
     pol = PackedPolicy(net, "cuda:0")
     pol.init_training(rows)
+    pol.gemm = gemm
     x = torch.randn(rows, 73, device="cuda:0")
     act = torch.rand(rows, 18, device="cuda:0") * 2 - 1
     olp = torch.randn(rows, device="cuda:0") - 20
@@ -316,9 +382,12 @@ def dry_run(a):
     K timed "steps", max over ranks, one JSON line on rank 0."""
     from fly_bproject_amd.dist import init_from_env
     os.environ.setdefault("FLY_DIST_BACKEND", "gloo")
-    rank, _, world = init_from_env("cpu")
+    if a.fail_rank == int(os.environ.get("RANK", "0")):
+        sys.exit(3)                                    # test hook: this rank dies before the rendezvous
+    rank, local_rank, world = init_from_env("cpu")
     if world != a.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    devices = gather_identities(device_identity(rank, local_rank, cuda=False), world)
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
@@ -334,7 +403,9 @@ def dry_run(a):
                           "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(float(tt[0]) / a.steps * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                           "data": "synthetic", "dry_run": True,
-                          "config": {"workload": "dry_run", "parallelism": "dp%d" % world}}), flush=True)
+                          "config": {"workload": "dry_run", "parallelism": "dp%d" % world, "devices": devices,
+                                     "world_size_seen": dist.get_world_size() if world > 1 else 1,
+                                     "backend": dist.get_backend() if world > 1 else None}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -344,32 +415,29 @@ DQN_FWD_FLOP = 2 * (73 * 256 + 256 * 256 + 256 * 18)            # 177 664 per sa
 DQN_BWD_DX_FLOP = 2 * (18 * 256 + 256 * 256)                     # 140 288
 
 
-def dqn_bench(a):
+def dqn_measure(n, mb, warmup, steps, kernel_reps):
     """BASELINE configs[4]: DQN, 32768 envs, HBM-resident replay ring (stated capacity), per-env eps-greedy and
     Huber-TD on the HIP kernels.  A "step" = one DQN.run(): act (one launch), env step, record into the ring,
     one update on `dqn_mini_batch` sampled steps x num_envs rows (dqn.py:102-126).  One rank (the reference DQN
-    has no data-parallel form and BASELINE names none)."""
+    has no data-parallel form and BASELINE names none).  Returns the line as a dict."""
     import ctypes as C
     from fly_bproject_amd import _lib
     from fly_bproject_amd.dqn import DQN
-    if a.gpus != 1:
-        sys.exit("bench.py --workload dqn runs on one GPU")
     torch.cuda.set_device(0)
     torch.manual_seed(0)
-    n, mb = a.dqn_envs, a.dqn_mini_batch
     cap = max(4 * mb, 64)
     with quiet():
         agent = DQN(make_args(n, dqn_mini_batch_size=mb, replay_steps=cap))
-        for _ in range(mb + a.warmup):                # fill the ring to the sample size (no updates yet), then `warmup` steps with updates
+        for _ in range(mb + warmup):                # fill the ring to the sample size (no updates yet), then `warmup` steps with updates
             agent.run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     with quiet():
-        for _ in range(a.steps):
+        for _ in range(steps):
             agent.run()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    assert int(agent.packed.step.item()) == a.warmup + a.steps, "an update was skipped"
+    assert int(agent.packed.step.item()) == warmup + steps, "an update was skipped"
     finite = all(torch.isfinite(p).all().item() for p in agent.q.parameters())
     lib = _lib.load()
     p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
@@ -379,11 +447,11 @@ def dqn_bench(a):
                                                   p(rp.next_obs[0]), p(rp.action[0]), p(rp.reward[0]), p(rp.done[0]), n,
                                                   C.c_float(0.99), C.c_float(1.0 / (n * mb)), p(agent._h1), p(agent._h2),
                                                   p(agent._dz3), p(agent._dz2), p(agent._dz1), p(agent._loss_part[0]), st),
-                          a.kernel_reps)
+                          kernel_reps)
     t_gw = _time_launches(lambda: lib.dqn_grad_w(p(rp.obs[0]), p(agent._h1), p(agent._h2), p(agent._dz1), p(agent._dz2),
-                                                 p(agent._dz3), n, p(agent._gw_ws), p(pk.G), 1, st), a.kernel_reps)      # a middle step of a batch: no reduction
+                                                 p(agent._dz3), n, p(agent._gw_ws), p(pk.G), 1, st), kernel_reps)      # a middle step of a batch: no reduction
     t_act = _time_launches(lambda: lib.dqn_act(p(pk.P), p(pk.PF), p(rp.obs[0]), n, p(agent._coin), p(agent._rand),
-                                               C.c_float(0.1), p(agent._dz3), None, st), a.kernel_reps)
+                                               C.c_float(0.1), p(agent._dz3), None, st), kernel_reps)
 
     def mfma(name, dur, flop, per_step):
         ach = flop / dur / 1e12
@@ -394,15 +462,79 @@ def dqn_bench(a):
                (2 * DQN_FWD_FLOP + DQN_BWD_DX_FLOP) * n, mb),
           mfma("dqn_grad_w_kernel (partials accumulate; one reduction per update)", t_gw, DQN_FWD_FLOP * n, mb),
           mfma("dqn_act_kernel (forward + argmax + eps-greedy)", t_act, DQN_FWD_FLOP * n, 1)]
+    capacity, rbytes = rp.capacity, rp.bytes
     agent.exit()
-    print(json.dumps({
-        "metric": "env-steps/sec (DQN act + env step + update), %d envs" % n, "value": round(n * a.steps / elapsed, 1),
-        "unit": "env-steps/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+    del agent
+    torch.cuda.empty_cache()
+    return {
+        "metric": "env-steps/sec (DQN act + env step + update), %d envs" % n, "value": round(n * steps / elapsed, 1),
+        "unit": "env-steps/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "fly_dqn_%denvs_batch%dsteps" % (n, mb), "num_envs_per_gpu": n, "sampled_steps_per_update": mb,
-                   "rows_per_update": n * mb, "replay_capacity_steps": rp.capacity, "replay_bytes": rp.bytes,
+                   "rows_per_update": n * mb, "replay_capacity_steps": capacity, "replay_bytes": rbytes,
                    "updates_per_env_step": 1, "parallelism": "dp1"},
-        "params_finite": finite, "roofline": ks[0], "kernels": ks[1:]}), flush=True)
+        "params_finite": finite, "roofline": ks[0], "kernels": ks[1:]}
+
+
+def dqn_bench(a):
+    if a.gpus != 1:
+        sys.exit("bench.py --workload dqn runs on one GPU")
+    print(json.dumps(dqn_measure(a.dqn_envs, a.dqn_mini_batch, a.warmup, a.steps, a.kernel_reps)), flush=True)
+
+
+GEMM_LABEL = {
+    "f32": "fp32 operands on v_mfma_f32_32x32x2_f32, fp32 accumulate",
+    "bf16x3": "fp32 operands split exactly into three bf16 terms each, six product terms on v_mfma_f32_32x32x16_bf16, fp32 "
+              "accumulate (error vs fp64 below the fp32 MFMA chain's: tools/bf16x3_gemm.hip) for EVERY MLP GEMM: rollout policy, "
+              "critic pass, the update's forward, dX chain and dW",
+}
+
+
+def time_exchange(agent, world, reps=50):
+    """The per-optimizer-step gradient exchange ALONE (297 KB all-reduce of the packed gradient), timed with HIP events on
+    the stream it is issued on; every rank runs it, the caller reports rank 0's figure.  Returns {variant: us per call}."""
+    out = {}
+    if world == 1:
+        return out
+    G = agent.policy.G
+    keep = G.clone()
+
+    def timed(fn):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return round(e0.elapsed_time(e1) * 1e3 / reps, 2)
+    out["rccl"] = timed(lambda: dist.all_reduce(G, op=dist.ReduceOp.SUM))
+    G.copy_(keep)
+    p2p, own = agent._p2p, False
+    if p2p is None:                       # the labelled variant: open + self-test it now (collective; votes on every stage)
+        try:
+            want = agent.dp_allreduce
+            agent.dp_allreduce = "auto"
+            p2p = agent._open_p2p(G.numel())
+            agent.dp_allreduce = want
+            own = p2p is not None
+        except Exception as e:      # noqa: BLE001
+            agent.p2p_selftest = "failed: %r" % (e,)
+            p2p = None
+    if p2p is not None:
+        out["p2p"] = timed(lambda: p2p.allreduce_(G))
+        ok = p2p.check()
+        flag = torch.tensor([1 if ok else 0], device=G.device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            out["p2p"] = None
+        if own:
+            p2p.close()
+    G.copy_(keep)
+    return out
 
 
 def main():
@@ -413,6 +545,8 @@ def main():
         return dry_run(a)
     if a.workload == "dqn":
         return dqn_bench(a)
+    if a.fail_rank == int(os.environ.get("RANK", "0")):
+        sys.exit(3)
     from fly_bproject_amd.dist import broadcast_policy, init_from_env
     from fly_bproject_amd.ppo import PPO
 
@@ -423,11 +557,15 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
+    devices = gather_identities(device_identity(rank, local_rank), world)
     torch.manual_seed(0)
     args = make_args(a.num_envs, sim_device=dev, rank=rank, world_size=world, dp_allreduce=a.dp_allreduce)
     with quiet():
         agent = PPO(args)
+        agent.policy.gemm = a.gemm
     broadcast_policy(agent)
+    with quiet():
+        agent.prepare()                              # peer windows + self-test (if asked for) BEFORE any warm-up or timing
     T = agent.rollout_size
 
     def iteration():
@@ -449,6 +587,7 @@ def main():
         iteration()
     fence()
     elapsed = time.perf_counter() - t0
+    steps_done = agent.optim_step
     # rollout-only rate (no update) for the breakdown
     agent.args.testing = True
     fence()
@@ -474,16 +613,15 @@ def main():
         tt = torch.tensor([elapsed, rollout_s], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, rollout_s = float(tt[0]), float(tt[1])
-    assert agent.optim_step == 75 * (a.warmup + a.steps), agent.optim_step
-    # Secondary, clearly labelled measurement (BASELINE configs[2]'s arithmetic): the same iteration with every MLP GEMM
-    # on the bf16 matrix pipe through three-term operand splits (fp32-accurate: tools/bf16x3_gemm.hip,
-    # tests/test_mlp_train_gpu.py::test_bf16x3_training_step_matches_fp32_path).  `value` above is the
-    # default fp32-MFMA path.
+    assert steps_done == 75 * (a.warmup + a.steps), steps_done
+    exchange_us = time_exchange(agent, world)
+    # Secondary, clearly labelled measurement: the same iteration with the OTHER arithmetic of the MLP GEMMs.
     alt = None
     main_gemm = agent.policy.gemm
-    if main_gemm == "f32" and not a.no_alt_gemm:
+    other = "f32" if main_gemm == "bf16x3" else "bf16x3"
+    if not a.no_alt_gemm:
         try:        # the secondary figure must never cost the primary one
-            agent.policy.gemm = "bf16x3"
+            agent.policy.gemm = other
             iteration()
             fence()
             a0 = time.perf_counter()
@@ -495,20 +633,26 @@ def main():
                 tt = torch.tensor([alt_s], device=dev, dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 alt_s = float(tt[0])
-            alt = {"gemm": "bf16x3 (three-term bf16 split of both operands, six product terms, fp32 accumulate) for EVERY MLP GEMM: "
-                           "rollout policy, critic pass, the update's forward, dX chain and dW",
+            alt = {"gemm": other, "arithmetic": GEMM_LABEL[other],
                    "value": round(world * a.num_envs * T * 2 / alt_s, 1), "unit": "env-steps/s", "steps": 2,
-                   "ms_per_step": round(alt_s / 2 * 1e3, 3)}
+                   "ms_per_step": round(alt_s / 2 * 1e3, 3), "update_path": agent.policy.update_path()}
         except Exception as e:      # noqa: BLE001
-            alt = {"gemm": "bf16x3", "error": repr(e)[:200]}
+            alt = {"gemm": other, "error": repr(e)[:200]}
         finally:
             agent.policy.gemm = main_gemm
     finite = all(torch.isfinite(p).all().item() for p in agent.net.parameters())
+    backend = dist.get_backend() if world > 1 else None
     agent_exchange = {"p2p": "one-shot peer-to-peer kernel over hipIpc windows (dp_allreduce_p2p)",
                       "rccl": "torch.distributed.all_reduce (%s)" % (os.environ.get("FLY_DIST_BACKEND") or "nccl = RCCL")}.get(
         agent.dp_allreduce, agent.dp_allreduce)
     ep_ret, ep_len, ep_cnt = agent.env.episode_stats()
+    refused = int(getattr(agent.policy, "fused_launch_failures", 0))
+    update_path = agent.policy.update_path()
+    p2p_selftest = getattr(agent, "p2p_selftest", None)
+    used_exchange = agent.dp_allreduce
     agent.exit()
+    del agent
+    torch.cuda.empty_cache()
 
     if rank == 0:
         env_steps = world * a.num_envs * T * a.steps
@@ -518,25 +662,39 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if main_gemm == "f32" else "f32 via bf16x3 operand splits (update forward + dX), fp32 accumulate",
+            "dtype": "f32" if main_gemm == "f32" else "f32 (bf16x3 operand split, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "fly_ppo_iteration_%denvs_T%d" % (a.num_envs, T),
                        "num_envs_per_gpu": a.num_envs, "rollout_size": T, "optimizer_steps_per_iteration": 75,
-                       "minibatch_samples": agent.mini_chunk_size * a.num_envs, "variant": "bigGrav",
-                       "parallelism": "dp%d" % world, "gemm": main_gemm,
+                       "minibatch_samples": (40960 // a.num_envs) * a.num_envs, "variant": "bigGrav",
+                       "parallelism": "dp%d" % world, "gemm": main_gemm, "arithmetic": GEMM_LABEL[main_gemm],
+                       "update_path": update_path,
+                       "devices": devices, "world_size_seen": dist.get_world_size() if world > 1 else 1, "backend": backend,
                        "grad_exchange": "none (1 rank)" if world == 1 else
                        ("%s, one call per optimizer step (75 per iteration), 297 KB" % agent_exchange)},
             "rollout_only_env_steps_per_s": round(world * a.num_envs * T / rollout_s, 1),
             "rollout_only_one_launch_per_rollout_env_steps_per_s": None if not persist_s else round(world * a.num_envs * T / persist_s, 1),
             "params_finite": finite,
+            "refused_steps": refused,                  # fused forward+backward launches whose optimizer steps were refused and redone
             "mean_episode_return": None if ep_cnt == 0 else round(ep_ret, 4),
             "mean_episode_length": None if ep_cnt == 0 else round(ep_len, 2), "episodes_finished": ep_cnt,
         }
+        if world > 1:
+            line["grad_exchange_us_per_step"] = exchange_us.get(used_exchange)   # the exchange `value` ran on
+            line["grad_exchange_variants_us"] = exchange_us         # rank 0, HIP events, the exchange alone
+            line["p2p_selftest"] = p2p_selftest
         if alt:
-            line["bf16x3_update"] = alt
-        ks = kernel_rooflines(a.num_envs, T, a.kernel_reps)
+            line["alt_gemm"] = alt
+        ks = kernel_rooflines(a.num_envs, T, a.kernel_reps, main_gemm)
         line["roofline"] = ks[0]                     # the dominant kernel of one iteration
         line["kernels"] = ks[1:]
+        if world == 1 and not a.no_dqn:
+            try:        # BASELINE configs[4], short and labelled: 32768 envs, stated ring, 3 timed env steps with one update each
+                d = dqn_measure(a.dqn_envs, a.dqn_mini_batch, 1, 3, max(5, a.kernel_reps // 4))
+                line["dqn"] = {k: d[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config",
+                                                 "params_finite", "roofline")}
+            except Exception as e:      # noqa: BLE001
+                line["dqn"] = {"error": repr(e)[:200]}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.num_envs)
         print(json.dumps(line), flush=True)

@@ -59,7 +59,7 @@ SYMBOLS = {
     "dp_ipc_export": [_P, _P],
     "dp_ipc_import": [_P, C.POINTER(_P)],
     "dp_ipc_close": [_P],
-    "dp_allreduce_p2p": [_P, _L, C.POINTER(_P), _I, _I, C.c_uint32, _P, _P],
+    "dp_allreduce_p2p": [_P, _L, C.POINTER(_P), _I, _I, C.c_uint32, _P, _L, _P],
 }
 
 

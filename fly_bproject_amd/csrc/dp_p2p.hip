@@ -18,6 +18,7 @@
 // 73 x 256 threads, far below one workgroup per CU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "flyhip.h"
 
 namespace {
@@ -35,7 +36,8 @@ struct P2PWindow {          // layout of one rank's window, offsets in bytes fro
 struct P2PTable { char* base[P2P_MAX_WORLD]; };
 
 __global__ __launch_bounds__(P2P_THREADS) void dp_allreduce_p2p_kernel(float* __restrict__ G, long n, P2PTable T, int rank,
-                                                                       int world, unsigned epoch, int* __restrict__ err)
+                                                                       int world, unsigned epoch, int* __restrict__ err,
+                                                                       long fail_slot, int poll_budget)
 {
     __shared__ int ok;
     const int tid = threadIdx.x, parity = (int)(epoch & 1u);
@@ -60,14 +62,20 @@ __global__ __launch_bounds__(P2P_THREADS) void dp_allreduce_p2p_kernel(float* __
     if (tid < world) {                                            // one lane per peer polls that peer's flag
         const unsigned* f = reinterpret_cast<const unsigned*>(T.base[tid] + P2PWindow::flag(parity, n));
         bool seen = false;
-        for (int poll = 0; poll < (1 << 22); ++poll) {
+        for (int poll = 0; poll < poll_budget; ++poll) {
             if (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == epoch) { seen = true; break; }
             __builtin_amdgcn_s_sleep(8);
         }
         if (!seen) { ok = 0; atomicMax(err, 1); }
     }
     __syncthreads();
-    if (!ok || q >= n4) return;
+    if (!ok) {
+        // a peer never published: G is NOT the sum.  Mark it invalid so that mlp_adam_* refuse it on this rank
+        // (fail closed); the host finds *err set at its next check and stops the run.
+        if (fail_slot >= 0 && q == fail_slot / 4) G[fail_slot] = 1.0f;
+        return;
+    }
+    if (q >= n4) return;
     __threadfence_system();
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int r = 0; r < world; ++r) {                             // rank order: identical on every rank
@@ -92,13 +100,23 @@ extern "C" hipError_t flyhip_p2p_alloc(int64_t n_floats, void** out)
 }
 
 extern "C" hipError_t flyhip_launch_p2p_allreduce(float* G, int64_t n, void* const* bases, int rank, int world,
-                                                  uint32_t epoch, int* err, void* stream)
+                                                  uint32_t epoch, int* err, int64_t fail_slot, void* stream)
 {
+    // how long a rank waits for a late peer (checkpoint save, first-use lazy loading, GC): 2^24 polls with s_sleep
+    // are several seconds; FLY_P2P_POLL_LOG2 overrides it
+    static int budget = 0;
+    if (!budget) {
+        const char* e = getenv("FLY_P2P_POLL_LOG2");
+        int lg = e ? atoi(e) : 24;
+        if (lg < 4) lg = 4;
+        if (lg > 30) lg = 30;
+        budget = 1 << lg;
+    }
     P2PTable T;
     for (int r = 0; r < P2P_MAX_WORLD; ++r) T.base[r] = r < world ? static_cast<char*>(bases[r]) : nullptr;
     const long n4 = n / 4;
     const unsigned grid = (unsigned)((n4 + P2P_THREADS - 1) / P2P_THREADS);
     hipLaunchKernelGGL(dp_allreduce_p2p_kernel, dim3(grid), dim3(P2P_THREADS), 0, (hipStream_t)stream, G, (long)n, T, rank, world,
-                       epoch, err);
+                       epoch, err, (long)fail_slot, budget);
     return hipGetLastError();
 }

@@ -46,7 +46,7 @@ extern "C" hipError_t flyhip_launch_dqn_adam(float* P, float* PF, float* PT, flo
                                              void* stream);
 extern "C" hipError_t flyhip_p2p_alloc(int64_t n_floats, void** out);
 extern "C" hipError_t flyhip_launch_p2p_allreduce(float* G, int64_t n, void* const* bases, int rank, int world,
-                                                  uint32_t epoch, int* err, void* stream);
+                                                  uint32_t epoch, int* err, int64_t fail_slot, void* stream);
 extern "C" int64_t flyhip_mlp_grad_workspace_floats(void);
 extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, const float* h2, const float* h3,
                                                const float* dz1, const float* dz2, const float* dz3, const float* dz4,
@@ -224,6 +224,7 @@ int ppo_rollout_all(FlyHandle h, const FlyBuffers* b, const float* params, const
     if (!params || !params_frag || !obs_ring || !eps_all || !var || !act_all || !logp_all || !v_ring || !reward_all)
         return fail(FLY_E_ARG, "ppo_rollout_all: null pointer");
     if (T <= 0 || T > (1 << 20)) return fail(FLY_E_ARG, "ppo_rollout_all: T out of range");
+    if (!b) return fail(FLY_E_ARG, "ppo_rollout_all: buffers are null");
     FlyBuffers bb = *b;
     bb.obs = obs_ring; bb.reward = reward_all;              // checked as present; the kernel walks the rows itself
     int rc = check_buffers(&bb, PH_SCALE | PH_RESET | PH_INTEGRATE | PH_OBS | PH_PROGRESS | PH_REWARD);
@@ -544,8 +545,9 @@ int dp_ipc_close(void* window)
 }
 
 int dp_allreduce_p2p(float* grad, int64_t n_floats, void* const* windows, int32_t rank, int32_t world, uint32_t epoch,
-                     int32_t* err, void* stream)
+                     int32_t* err, int64_t fail_slot, void* stream)
 {
+    if (fail_slot >= n_floats) return fail(FLY_E_ARG, "dp_allreduce_p2p: fail_slot outside the buffer");
     if (!grad || !windows || !err) return fail(FLY_E_ARG, "dp_allreduce_p2p: null pointer");
     if (world < 1 || world > 16 || rank < 0 || rank >= world) return fail(FLY_E_ARG, "dp_allreduce_p2p: bad rank / world (max 16)");
     if (n_floats <= 0 || (n_floats & 3)) return fail(FLY_E_ARG, "dp_allreduce_p2p: n_floats must be a positive multiple of 4");
@@ -553,7 +555,7 @@ int dp_allreduce_p2p(float* grad, int64_t n_floats, void* const* windows, int32_
     if (epoch == 0) return fail(FLY_E_ARG, "dp_allreduce_p2p: epochs start at 1");
     for (int r = 0; r < world; ++r)
         if (!windows[r]) return fail(FLY_E_ARG, "dp_allreduce_p2p: window %d is null", r);
-    hipError_t e = flyhip_launch_p2p_allreduce(grad, n_floats, windows, rank, world, epoch, err, stream);
+    hipError_t e = flyhip_launch_p2p_allreduce(grad, n_floats, windows, rank, world, epoch, err, fail_slot, stream);
     if (e != hipSuccess) return hip_fail(e, "dp_allreduce_p2p launch");
     return FLY_OK;
 }

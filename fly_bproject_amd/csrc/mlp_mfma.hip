@@ -93,12 +93,9 @@ __global__ __launch_bounds__(THREADS, WPS) void rollout_all_kernel(
     // the variance of the CURRENT row lives in LDS and is decayed once per step (ppo.py:236-237): the same sequence of
     // fp32 operations as the per-step form, O(1) per step however long the rollout (T = 40 960 at 16 envs)
     float* varcur = lds + ARENA;
-    if (threadIdx.x < MLP_NACT) {
-        float v = var[threadIdx.x];
-        const int pending = rows_applied ? -*rows_applied : 0;         // rows of this rollout not yet applied to `var` (0 at its start)
-        for (int i = 0; i < pending; ++i) v = fmaxf(var_min, v - var_decay);
-        varcur[threadIdx.x] = v;
-    }
+    // the launch is the FIRST device work of its rollout: *rows_applied was zeroed just before it and no bookkeeping
+    // flush can run until it has finished, so `var` is exactly the variance of row 0
+    if (threadIdx.x < MLP_NACT) varcur[threadIdx.x] = var[threadIdx.x];
     FlyRegs st;
     fly_load<PH_ALL>(st, c, b, blockIdx.x);
     __syncthreads();

@@ -22,6 +22,7 @@ OFF_B3 = OFF_W3 + H3 * H2
 OFF_W4 = OFF_B3 + H3
 OFF_B4 = OFF_W4 + OUT * H3
 PACKED = OFF_B4 + OUT                      # 74272
+ERR_SLOT = OFF_W1 + 76                     # a masked padding element of W1: the "this gradient is invalid" mark (csrc/mlp_grad_w.inc)
 OFF_F1 = 0
 OFF_F2 = OFF_F1 + H1 * IN_PAD
 OFF_F3 = OFF_F2 + H2 * H1
@@ -342,6 +343,12 @@ class PackedPolicy:
                                         p(d["dz3"]), p(d["dz4"]), C.c_int64(n), p(self.workspace), p(self.G), *nm,
                                         p(self.tile_wait_error), C.c_int(1 if self.gemm == "bf16x3" else 0), st),
                    "mlp_grad_w")
+
+    def update_path(self):
+        """Which launches one optimizer step is made of (for the bench line)."""
+        if self.fuse_fwd_bwd:
+            return "mlp_forward_backward (one launch, per-tile flags) + mlp_grad_w (+reduce) + mlp_adam_step, gemm=" + self.gemm
+        return "mlp_forward + mlp_backward_dx + mlp_grad_w (+reduce) + mlp_adam_step, gemm=" + self.gemm
 
     def loss_value(self, n):
         """ppo.py:194/:197 scalar of the last minibatch_grad call (diagnostics; one small reduction)."""

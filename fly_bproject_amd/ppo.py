@@ -303,8 +303,7 @@ class PPO:
         pol = self.policy
         sync_grads = self.world_size > 1 and self.dp_mode == "grad_allreduce"
         slices = [(j - mc, j) for _ in range(self.epoch) for j in range(mc, self.rollout_size, mc)]   # 5 x 15 (Q3)
-        if sync_grads and self.dp_allreduce in ("p2p", "auto") and self._p2p is None:
-            self._p2p = self._open_p2p(pol.G.numel())
+        self.prepare()                   # idempotent; callers that time the update call it themselves before warm-up
 
         def run(todo):
             for k, j in todo:
@@ -341,7 +340,9 @@ class PPO:
             run(slices[len(slices) - short:])
         self.optim_step += len(slices)
         if self._p2p is not None and not self._p2p.check():
-            raise _lib.FlyHipError("dp_allreduce_p2p: a rank never published its gradient (bounded wait expired)")
+            # fatal by design: this rank's optimizer refused the un-reduced gradients (fail closed), its peers cannot know
+            raise _lib.FlyHipError("dp_allreduce_p2p: a rank never published its gradient (bounded wait expired; "
+                                   "FLY_P2P_POLL_LOG2 raises the budget, --dp_allreduce rccl avoids the kernel)")
         if self.world_size > 1 and not sync_grads:
             # dp_mode "param_average": ONE exchange per PPO update (BASELINE's north_star wording) --
             # ranks take their 75 optimizer steps locally, then parameters and Adam moments are
@@ -351,34 +352,51 @@ class PPO:
                 buf.div_(self.world_size)
             pol.refresh()
 
+    def prepare(self):
+        """Everything an update needs that is not part of an update: with data-parallel ranks and `dp_allreduce` "p2p" or
+        "auto", open the peer windows and self-test the one-shot exchange against the collective.  A COLLECTIVE call (every
+        rank makes it, in the same place); idempotent.  `bench.py` calls it before the warm-up so that none of it lands in a
+        timed region; `_update_hip` calls it too, so a plain `run()` loop needs nothing extra."""
+        if getattr(self, "_prepared", False):
+            return
+        self._prepared = True
+        self.p2p_selftest = None
+        sync_grads = self.world_size > 1 and self.dp_mode == "grad_allreduce"
+        if sync_grads and self.update_backend == "hip" and self.dp_allreduce in ("p2p", "auto"):
+            self._p2p = self._open_p2p(self.policy.G.numel())
+
     def _open_p2p(self, n):
         """Open the peer windows and hold the one-shot kernel to the collective on random data (3 epochs, both
-        parities).  Every rank takes the same decision (the verdicts are all-reduced): on any failure -- no IPC
-        between these devices, a rank that never publishes, a wrong sum -- "auto" falls back to RCCL, "p2p" raises."""
+        parities).  Every rank takes the same decision at every stage (`P2PAllReduce` votes inside its constructor, the
+        self-test verdicts are all-reduced): on any failure -- no IPC between these devices, a wrong sum, a rank that
+        never publishes -- "auto" falls back to RCCL on every rank together, "p2p" raises on every rank together."""
         import torch.distributed as dist
-        from .dist import P2PAllReduce
-        ok, p2p, why = 1, None, ""
+        from .dist import P2PAllReduce, P2PUnavailable
+        from .policy import ERR_SLOT
+        p2p, why = None, ""
         try:
-            p2p = P2PAllReduce(n, self.device)
-        except Exception as e:      # noqa: BLE001
-            ok, why = 0, repr(e)[:200]
-        flag = torch.tensor([ok], device=self.device, dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
+            p2p = P2PAllReduce(n, self.device, fail_slot=ERR_SLOT)          # raises on ALL ranks or on none
+        except P2PUnavailable as e:
+            why = str(e)[:300]
+        good = p2p is not None
+        if good:
+            flag = torch.ones(1, device=self.device, dtype=torch.int32)
             gen = torch.Generator(device=self.device)
             gen.manual_seed(7 + int(getattr(self.args, "rank", 0)))
             for _ in range(3):
                 a = torch.randn(n, device=self.device, generator=gen)
+                a[ERR_SLOT] = 0.0
                 b = a.clone()
                 p2p.allreduce_(a)
                 dist.all_reduce(b, op=dist.ReduceOp.SUM)
-                good = p2p.check() and torch.allclose(a, b, rtol=1e-5, atol=1e-5)
-                flag.fill_(1 if good else 0)
+                mine = p2p.check() and torch.allclose(a, b, rtol=1e-5, atol=1e-5)
+                flag.fill_(1 if mine else 0)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 if int(flag.item()) != 1:
-                    why = "self-test against the collective failed"
+                    good, why = False, "self-test against the collective failed"
                     break
-        if int(flag.item()) == 1:
+        self.p2p_selftest = "passed" if good else ("failed: " + (why or "a peer failed"))
+        if good:
             self.dp_allreduce = "p2p"
             return p2p
         if p2p is not None:
@@ -425,13 +443,13 @@ class PPO:
             bufs.append((self._obs_rows[t + 1].data_ptr(), self._reward_rows[t].data_ptr()))
         self._fwd_args, self._buf_ptrs, self._step_args = fwd, bufs, step
         self._graphs = {}                                            # captured steps hold the old pointers
-        # one launch per env step unless captured graphs or a bf16x3 inference body are asked for
-        # one launch per env step, eager or captured
+        # one launch per env step (policy + sampling + env step), eager or captured; FLY_FUSE_ROLLOUT_STEP=0 keeps the
+        # two-launch form (mlp_forward_sample + fly_step) for the A/B test
         self.fuse_rollout_step = os.environ.get("FLY_FUSE_ROLLOUT_STEP", "1") != "0"
         self._args_infer_gemm = pol.gemm_infer
 
     def _launch_step(self, t):
-        """The device work of one env step (ppo.py:213-237): two launches, no host logic.  Rows of
+        """The device work of one env step (ppo.py:213-237): ONE launch (`ppo_rollout_step`), no host logic.  Rows of
         the rollout are written in place (obs row t+1, action/log-prob/reward rows t); the score and
         variance bookkeeping of the step is deferred (`_flush_bookkeeping`)."""
         lib, env = self._lib, self.env

@@ -414,8 +414,11 @@ int dqn_adam_soft_update(float* params, float* params_frag, float* params_t_frag
  * bytes to hand to the peers by any means), opens the peers' (dp_ipc_import) and passes the `world` window
  * pointers -- its own at index `rank` -- in rank order.  dp_allreduce_p2p(grad, ...) with epoch = 1, 2, 3, ...
  * (the same on every rank): one launch publishes grad, waits for every rank's flag of this epoch (bounded:
- * *err = 1 instead of a hang) and leaves the sum over ranks, added in rank order (bit-identical on every rank),
- * in grad.  world <= 16.
+ * *err = 1 instead of a hang; the budget is 2^FLY_P2P_POLL_LOG2 polls, default 2^24 = several seconds) and leaves
+ * the sum over ranks, added in rank order (bit-identical on every rank), in grad.  world <= 16.
+ * fail_slot >= 0: a rank whose wait expired also writes 1.0f to grad[fail_slot] (mlp_adam_step's "invalid
+ * gradient" mark, element 76 of the packed gradient), so its optimizer launch refuses the un-reduced gradient;
+ * the caller then reads *err (nonzero) and stops: a lost peer is fatal for the run, it is never papered over.
  */
 int dp_p2p_alloc(int64_t n_floats, void** window_out);
 int dp_p2p_free(void* window);
@@ -423,7 +426,7 @@ int dp_ipc_export(const void* window, uint8_t handle_out[64]);
 int dp_ipc_import(const uint8_t handle[64], void** window_out);
 int dp_ipc_close(void* window);
 int dp_allreduce_p2p(float* grad, int64_t n_floats, void* const* windows, int32_t rank, int32_t world,
-                     uint32_t epoch, int32_t* err, void* stream);
+                     uint32_t epoch, int32_t* err, int64_t fail_slot, void* stream);
 
 #ifdef __cplusplus
 }

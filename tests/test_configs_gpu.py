@@ -1,5 +1,6 @@
 """GPU (-m gpu): every configuration BASELINE.json lists, at its full size, through the product path.
 
+  configs[0]  16 envs, T = 40 960 (the reference's own CPU-runnable shape) through the PRODUCT path             (here)
   configs[1]  4096 envs, fp32                         -> tests/test_ppo_gpu.py (two iterations)
   configs[2]  16384 envs, bf16(x3) MLP on the bf16 MFMA pipe + hipGraph-captured rollout step   (here)
   configs[3]  8 x 8192 envs, gradient all-reduce      -> 8192-env shard here; ranks in tests/test_dist_gpu.py
@@ -100,6 +101,43 @@ def test_config2_16384_envs_bf16x3_with_captured_rollout():
     assert moved > 0.1 and dev <= 0.10 * moved, (dev, moved)
     assert float((out["bf16x3"] - out["f32"]).abs().max()) <= 8e-3
     assert not torch.equal(out["f32"], out["bf16x3"])                                 # a different arithmetic did run
+    agent.exit()
+
+
+def test_config0_shape_16_envs_one_iteration():
+    """configs[0]'s shape on the product path: 16 envs -> mini_chunk_size 2560, T = 40 960 (ppo.py:118-122).  One whole PPO
+    iteration: 40 960 one-launch env steps, make_data with the wave-scan GAE the host selects for few envs x long rollouts
+    (equal to the reference's sequential loop, restated by the oracle, on this very rollout, to the scan's stated 2e-5), then
+    75 optimizer steps of 40 960 rows."""
+    from fly_bproject_amd.ppo import PPO
+    from oracle import oracle as O
+    torch.manual_seed(0)
+    with _quiet():
+        agent = PPO(make_args(16))
+    assert agent.mini_chunk_size == 2560 and agent.rollout_size == 40960
+    T = agent.rollout_size
+    with _quiet():
+        for _ in range(T - 1):
+            agent.run()
+        agent._launch_step(T - 1)                      # the rollout's last env step without the update that run() would start
+        agent._flush_bookkeeping()
+    torch.cuda.synchronize()
+    assert agent._v_have == T
+    np.testing.assert_allclose(float(agent.action_var[0]), max(0.01, 0.2 - T * 1e-5), rtol=1e-4)    # 0.2 -> 0.01 floor at step 19 000
+    _, _, _, target, adv = agent.make_data()
+    torch.cuda.synchronize()
+    values, done_f = agent._keep
+    t_o, a_o = O.td_gae(agent.all_reward[..., 0].cpu().numpy(), values[:T, :, 0].cpu().numpy(), values[1:, :, 0].cpu().numpy(),
+                        done_f.view(-1).cpu().numpy())
+    assert np.array_equal(target[..., 0].cpu().numpy(), t_o)                           # the TD target has no recurrence: bit-exact
+    np.testing.assert_allclose(adv[..., 0].cpu().numpy(), a_o, rtol=2e-5, atol=2e-5)   # scan mode re-associates the chunk carries
+    with _quiet():
+        agent.update()
+    torch.cuda.synchronize()
+    assert agent.optim_step == 75 and int(agent.policy.step.item()) == 75
+    for k, v in _snapshot(agent).items():
+        assert torch.isfinite(v.float()).all(), k
+    assert int(agent.policy.tile_wait_error.item()) == 0
     agent.exit()
 
 

@@ -119,6 +119,22 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["config"]["parallelism"] == "dp2"
     assert lines[0]["ms_per_step"] >= 19.0          # rank 1 sleeps 20 ms per step: the MAX over ranks is reported
+    cfg = lines[0]["config"]                        # who took part: one identity per rank, gathered over the process group
+    assert cfg["world_size_seen"] == 2 and cfg["backend"] == "gloo" and len(cfg["devices"]) == 2
+    assert [d["rank"] for d in cfg["devices"]] == [0, 1] and cfg["devices"][0]["pid"] != cfg["devices"][1]["pid"]
+
+
+def test_bench_dead_rank_fails_fast():
+    """A rank that dies at start (here: exit code 3 before the rendezvous) must not leave its siblings waiting in a
+    collective until some outer time limit: the parent polls all children, terminates the rest and returns non-zero
+    within seconds, naming the rank."""
+    import time
+    t0 = time.time()
+    r, lines = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--dry_run", "--fail_rank", "1"], timeout=120)
+    took = time.time() - t0
+    assert r.returncode == 3 and not lines, (r.returncode, r.stderr[-1000:])
+    assert took < 30.0, took
+    assert "rank 1 exited with code 3" in r.stderr
 
 
 def test_bench_refuses_a_launcher_that_disagrees_with_gpus():

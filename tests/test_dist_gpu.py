@@ -96,12 +96,14 @@ def test_two_ranks_one_gpu(tmp_path, dp_mode):
     assert a["finite"] and b["finite"]
     assert torch.equal(a["P"], b["P"]) and torch.equal(a["PF"], b["PF"])     # replicas in lock step
     assert not torch.equal(a["acts"], b["acts"])                              # but different rollouts
-    if dp_mode == "p2p":        # the one-shot kernel sums in rank order like gloo's two-rank sum: same parameters as the collective
-        ref = torch.load(tmp_path.parent / "ref_P.pt", weights_only=True) if (tmp_path.parent / "ref_P.pt").exists() else None
-        if ref is not None:
-            assert torch.equal(a["P"], ref)
-    elif dp_mode == "grad_allreduce":
-        torch.save(a["P"], tmp_path.parent / "ref_P.pt")
+    if dp_mode == "p2p":
+        # the one-shot kernel sums in rank order like gloo's two-rank sum: the SAME run through the collective, made right
+        # here (no dependence on another parametrisation or on test order), ends at the same parameters bit for bit
+        ref_dir = tmp_path / "collective"
+        ref_dir.mkdir()
+        mp.spawn(_worker, args=(2, _free_port(), str(ref_dir), "grad_allreduce"), nprocs=2, join=True)
+        ref = torch.load(ref_dir / "r0.pt", weights_only=True)
+        assert torch.equal(a["P"], ref["P"]) and torch.equal(a["acts"], ref["acts"])
 
 
 def test_bench_gpus_2_on_one_gpu():
@@ -114,7 +116,7 @@ def test_bench_gpus_2_on_one_gpu():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-                        "--num_envs", "2048", "--no_cpu_baseline", "--no_alt_gemm", "--kernel_reps", "5"],
+                        "--num_envs", "2048", "--no_cpu_baseline", "--no_alt_gemm", "--no_dqn", "--kernel_reps", "5"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -123,3 +125,11 @@ def test_bench_gpus_2_on_one_gpu():
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["params_finite"]
     T = line["config"]["rollout_size"]
     assert abs(line["value"] * line["ms_per_step"] * 1e-3 - 2 * 2048 * T) < 1e-3 * 2 * 2048 * T
+    # the line proves who took part: one entry per rank with its device identity, the world size the process group reports,
+    # the exchange that carried `value` (the collective) with its own HIP-event timing, and the labelled peer-to-peer variant
+    cfg = line["config"]
+    assert cfg["world_size_seen"] == 2 and len(cfg["devices"]) == 2 and {d["rank"] for d in cfg["devices"]} == {0, 1}
+    assert all(d["name"] and d["pid"] for d in cfg["devices"]) and cfg["devices"][0]["pid"] != cfg["devices"][1]["pid"]
+    assert cfg["grad_exchange"].startswith("torch.distributed.all_reduce")
+    assert line["grad_exchange_us_per_step"] > 0 and "rccl" in line["grad_exchange_variants_us"]
+    assert line["refused_steps"] == 0

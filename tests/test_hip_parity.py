@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import oracle as O
-from tests.hip_helpers import cuda, make_env, pose_actions, pull_state, push_state
+from tests.hip_helpers import cuda, make_args, make_env, pose_actions, pull_state, push_state
 
 pytestmark = pytest.mark.gpu
 OBS_TOL = dict(rtol=3e-6, atol=3e-6)
@@ -548,4 +548,96 @@ def test_integrator_against_closed_form_recurrences():
         # velocity tolerance
         np.testing.assert_allclose(got.dof_vel, qd, rtol=5e-3, atol=5e-3)
         assert np.all(got.contact == 0)
+        env.exit()
+
+
+@pytest.mark.parametrize("variant", ["bigGrav", "lowGrav"])
+def test_contact_model_against_closed_form_recurrences(variant):
+    """The CONTACT law of FlyDyn (oracle/fly_physics.inc header, step 2) held to its own equations with no code shared
+    with the oracle.  `FlyConfig` is data, so the body is reduced to cases whose discrete recurrence can be written in
+    float64 numpy: identity orientation, legs folded clear of the plane (zero-length segments attached ABOVE the body),
+    joints resting at their targets, and
+      (A) "drop": the five abdomen points on the body z-axis at different offsets a_k, purely vertical motion -- per
+          point d_k = a_k - z, fn_k = max(kc d_k (1 - cdamp vz), 0) for d_k > 0, no tangential force, no torque (r x f = 0
+          for collinear r and f): vz <- clamp((vz + h (sum fn_k / m + g)) (1 - h lin_damp)), z <- z + h vz.  Initial
+          heights / speeds cover free approach, partial contact (some points in, some out), deep penetration, fast
+          rebound (1 - cdamp vz < 0: the clamp at zero) and the static depth d = m |g| / (n kc) that the drop settles to;
+      (B) "slide": all five points at the body origin (no lever arm, so friction exerts no torque), tangential velocity
+          -- ft = min(cvisc |u_t|, mu fn) per point, direction -u_t / (|u_t| + 1e-9): both the viscous and the capped
+          (sliding) regime, coupled to the vertical recurrence through fn."""
+    from fly_bproject_amd.fly import Fly
+    from fly_bproject_amd.params import default_params
+    n, steps = 64, 3
+    rng = np.random.default_rng(11)
+    for case in ("drop", "slide"):
+        prm = default_params(n, variant)
+        prm.femur_len, prm.tibia_len = 0.0, 0.0
+        for l in range(6):
+            prm.leg_attach[l][:] = (0.0, 0.0, 1.0e4)             # leg tips far above the body: never in contact
+        offs = np.array([0.25, 0.30, 0.35, 0.40, 0.45]) if case == "drop" else np.zeros(5)
+        for k in range(5):
+            prm.abdomen_pts[k][:] = (0.0, 0.0, -float(offs[k]))
+        env = Fly(make_args(n, variant=variant), params=prm)
+        m, g, kc, cd, mu, cv = (float(prm.mass), float(prm.gravity), float(prm.kc), float(prm.cdamp), float(prm.mu), float(prm.cvisc))
+        h = float(prm.dt) / int(prm.substeps)
+        ld, vlim = 1.0 - h * float(prm.lin_damp), float(prm.max_lin_vel)
+        d_static = m * abs(g) / (5 * kc)
+        s = O.EnvState(n)
+        s.root[:] = 0
+        s.root[:, 6] = 1.0
+        top = offs.max()
+        # heights: from well above first touch to deep inside; a few envs exactly at the static depth of five equal points
+        s.root[:, 2] = top + rng.uniform(-6.0 * d_static - 0.05, 0.2, n)
+        s.root[:, 9] = rng.uniform(-30.0, 30.0, n)               # |vz| > 1 / cdamp = 20 reaches the clamp at zero
+        if case == "slide":
+            s.root[:8, 2] = -d_static                            # resting depth: gravity and five springs balance
+            s.root[:8, 9] = 0.0
+            ut = np.concatenate([rng.uniform(0.0, 5.0, n // 2), rng.uniform(50.0, 800.0, n - n // 2)])   # viscous / capped
+            ang = rng.uniform(0, 2 * np.pi, n)
+            s.root[:, 7], s.root[:, 8] = ut * np.cos(ang), ut * np.sin(ang)
+        pose = np.array(prm.dof_pose[:], np.float32)
+        s.dof_pos[:] = pose
+        s.dof_vel[:] = 0
+        s.targets[:] = pose
+        s.reset[:] = 0
+        push_state(env, s)
+        for _ in range(steps):
+            env.simulate()
+        got = pull_state(env)
+        z = s.root[:, 2].astype(np.float64).copy()
+        xy = np.zeros((n, 2))
+        v = s.root[:, 7:10].astype(np.float64).copy()
+        seen_partial = seen_clamp = seen_cap = seen_visc = 0
+        fn_last = np.zeros((n, 5)); ft_last = np.zeros((n, 5, 2))
+        for _ in range(steps * int(prm.substeps)):
+            d = offs[None, :] - z[:, None]                       # penetration depth of each point
+            inside = d > 0
+            fn = np.where(inside, np.maximum(kc * d * (1.0 - cd * v[:, 2:3]), 0.0), 0.0)
+            utn = np.hypot(v[:, 0], v[:, 1])
+            ft = np.where(inside, np.minimum(cv * utn[:, None], mu * fn), 0.0)
+            sc = ft / (utn[:, None] + 1e-9)
+            fxy = -sc[:, :, None] * v[:, None, :2]
+            seen_partial += int(np.any(inside.any(1) & ~inside.all(1)))
+            seen_clamp += int(np.any(inside & (kc * d * (1.0 - cd * v[:, 2:3]) < 0)))
+            seen_cap += int(np.any(inside & (cv * utn[:, None] > mu * fn) & (utn[:, None] > 0)))
+            seen_visc += int(np.any(inside & (cv * utn[:, None] < mu * fn) & (utn[:, None] > 0)))
+            fn_last, ft_last = fn, fxy
+            F = np.concatenate([fxy.sum(1), fn.sum(1, keepdims=True)], axis=1)
+            v = (v + h * (F / m + np.array([0.0, 0.0, g]))) * ld
+            v = np.clip(v, -vlim, vlim)
+            xy = xy + h * v[:, :2]
+            z = z + h * v[:, 2]
+        # the cases the docstring promises did occur
+        assert seen_clamp > 0 and (seen_partial > 0 if case == "drop" else (seen_cap > 0 and seen_visc > 0)), (case, variant)
+        np.testing.assert_allclose(got.root[:, 2], z, rtol=2e-4, atol=2e-4, err_msg="%s %s z" % (case, variant))
+        np.testing.assert_allclose(got.root[:, :2], xy, rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(got.root[:, 7:10], v, rtol=5e-3, atol=5e-3)
+        np.testing.assert_allclose(got.contact[:, :5, 2], fn_last, rtol=2e-3, atol=2e-3 * max(1.0, m * abs(g)))
+        np.testing.assert_allclose(got.contact[:, :5, :2], ft_last, rtol=5e-3, atol=5e-3 * max(1.0, m * abs(g)))
+        assert np.all(got.contact[:, 5:] == 0)                    # the folded legs never touch
+        # no lever arm or collinear force: orientation and spin stay exactly at rest
+        assert np.abs(got.root[:, 3:6]).max() < 1e-6 and np.abs(got.root[:, 10:13]).max() < 1e-5
+        np.testing.assert_allclose(got.dof_pos, np.broadcast_to(pose, (n, 18)), atol=1e-6)
+        if case == "slide":       # a body placed at the static depth with no vertical speed stays there (until friction is all that acts)
+            np.testing.assert_allclose(got.root[:8, 2], -d_static, rtol=1e-3, atol=1e-5)
         env.exit()

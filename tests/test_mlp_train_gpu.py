@@ -20,7 +20,10 @@ def _bare_agent(net, var):
     return p
 
 
-def _setup(n, seed, sd=None):
+GEMMS = ["f32", "bf16x3"]     # both arithmetics are held to autograd and to the reference's g7 golden at the SAME tolerances
+
+
+def _setup(n, seed, sd=None, gemm=None):
     from fly_bproject_amd.policy import PackedPolicy
     from fly_bproject_amd.ppo import Net, diag_gauss_logprob
     torch.manual_seed(seed)
@@ -31,6 +34,8 @@ def _setup(n, seed, sd=None):
     ref.load_state_dict({k: v.clone() for k, v in net.state_dict().items()})
     pol = PackedPolicy(net, DEV)
     pol.init_training(max(n, 32))
+    if gemm is not None:
+        pol.gemm = gemm
     g = torch.Generator(device=DEV).manual_seed(seed)
     x = torch.randn(n, 73, device=DEV, generator=g)
     var = torch.full((18,), 0.15, device=DEV)
@@ -43,9 +48,10 @@ def _setup(n, seed, sd=None):
     return net, ref, pol, (x, action, old_logp, adv, target, var)
 
 
+@pytest.mark.parametrize("gemm", GEMMS)
 @pytest.mark.parametrize("n", [16, 4099, 40960])
-def test_minibatch_gradient_matches_autograd(n):
-    net, ref, pol, (x, action, old_logp, adv, target, var) = _setup(n, 3)
+def test_minibatch_gradient_matches_autograd(n, gemm):
+    net, ref, pol, (x, action, old_logp, adv, target, var) = _setup(n, 3, gemm=gemm)
     pol.minibatch_grad(x, action, old_logp, adv, target, var, 0.2)
     loss_hip = float(pol.loss_value(n))
     agent = _bare_agent(ref, var)
@@ -98,13 +104,15 @@ def test_adam_clip_step_matches_torch():
     assert torch.all(pol.W4[18, :64] == 0) and torch.all(pol.b4[19:] == 0)
 
 
-def test_update_matches_reference_golden(golden):
+@pytest.mark.parametrize("gemm", GEMMS)
+def test_update_matches_reference_golden(golden, gemm):
     """75 optimizer steps of the reference's PPO.update (g7: T=32, N=8, mini_chunk 2) from the same
-    initial weights end at the same weights (fp32 tolerance of the CPU-oracle test)."""
+    initial weights end at the same weights (fp32 tolerance of the CPU-oracle test); the first minibatch's loss,
+    gradient norm and every parameter's gradient equal the reference's recorded autograd values."""
     g = golden("g7_update")
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)   # noqa: E731
     sd = {k[3:]: t(g[k]) for k in g.files if k.startswith("w0_")}
-    net, ref, pol, _ = _setup(16, 0, sd=sd)
+    net, ref, pol, _ = _setup(16, 0, sd=sd, gemm=gemm)
     obs, acts, logp = t(g["obs"]), t(g["acts"]), t(g["log_prob"])
     target, adv, var = t(g["target"]), t(g["adv"]), t(g["action_var"])
     T, N, mc = 32, 8, 2
@@ -125,6 +133,11 @@ def test_update_matches_reference_golden(golden):
             k = j
     assert steps == 75
     np.testing.assert_allclose(first[0], float(g["loss0"]), rtol=2e-5)
+    coef = min(1.0, 1.0 / (float(g["gradnorm0"]) + 1e-6))      # g0_* were recorded after clip_grad_norm_ scaled them in place
+    for name, view in pol.views.items():         # the reference's own gradients of the first minibatch (ppo.py:197-198)
+        idx = torch.arange(first[1].numel(), device=DEV).as_strided(view.shape, view.stride(), view.storage_offset())
+        want = g["g0_" + name]
+        np.testing.assert_allclose(first[1][idx].cpu().numpy() * coef, want, rtol=0, atol=2e-4 * float(np.abs(want).max()) + 1e-9, err_msg=name)
     for k, p in net.state_dict().items():
         np.testing.assert_allclose(p.cpu().numpy(), g["w1_" + k], rtol=2e-3, atol=2e-4, err_msg=k)
 

@@ -63,11 +63,15 @@ def test_action_var_schedule_and_done_mask():
     agent.exit()
 
 
+GEMMS = ["f32", "bf16x3"]     # both arithmetics of the MLP GEMMs are held to the reference's golden vectors at the SAME tolerance
+
+
+@pytest.mark.parametrize("gemm", GEMMS)
 @pytest.mark.parametrize("n", [1, 31, 32, 33, 8192, 40960 + 7])
-def test_mfma_forward_matches_torch_and_oracle(golden, n):
-    """mlp_forward (fp32 MFMA) vs torch fp32 on the same weights; tolerance 2e-5 rel/abs (k-order and
-    fma chaining differ from a BLAS dot product, nothing else), and vs the reference's own Net.pi/.v
-    outputs recorded in g4."""
+def test_mfma_forward_matches_torch_and_oracle(golden, n, gemm):
+    """mlp_forward (fp32 MFMA, and the bf16x3 operand-split arithmetic) vs torch fp32 on the same weights; tolerance
+    2e-5 rel/abs (k-order and fma chaining differ from a BLAS dot product, nothing else), and vs the reference's own
+    Net.pi/.v outputs recorded in g4."""
     from fly_bproject_amd.policy import PackedPolicy
     from fly_bproject_amd.ppo import Net
     g = golden("g4_net")
@@ -76,6 +80,7 @@ def test_mfma_forward_matches_torch_and_oracle(golden, n):
     ref = Net(73, 18).to("cuda:0")
     ref.load_state_dict(net.state_dict())
     pol = PackedPolicy(net, "cuda:0")
+    pol.gemm = gemm
     net._policy = pol
     gen = torch.Generator(device="cuda:0").manual_seed(n)
     x = torch.randn(n, 73, device="cuda:0", generator=gen) * 1.5
@@ -91,7 +96,7 @@ def test_mfma_forward_matches_torch_and_oracle(golden, n):
             np.testing.assert_allclose(net.v(xg).cpu().numpy(), g["v"], rtol=2e-5, atol=2e-5)
         saves = {"out": torch.empty(n, 32, device="cuda:0"), "h1": torch.empty(n, 256, device="cuda:0"),
                  "h2": torch.empty(n, 128, device="cuda:0"), "h3": torch.empty(n, 128, device="cuda:0")}
-        pol.forward(x, saves=saves)
+        pol.forward(x, saves=saves)      # saves given: the UPDATE's forward arithmetic (pol.gemm)
         with torch.no_grad():
             h1 = ref.shared_net[1](ref.shared_net[0](x)); h2 = ref.shared_net(x)
             h3 = torch.cat([ref.to_mean[1](ref.to_mean[0](h2)), ref.to_value[1](ref.to_value[0](h2))], dim=1)
@@ -170,10 +175,40 @@ def test_graph_replay_matches_eager_rollout():
                 assert a == b, (mode, i)
 
 
+def test_one_launch_per_rollout_in_training_mode():
+    """`persistent_rollout` (ppo_rollout_all) with the variance DECAYING (training mode, 1e-5 per step) over two whole
+    iterations, updates included, with the score print (and its bookkeeping flush) landing inside rollouts while the device
+    has run ahead: rollout tensors, action_var and every parameter equal the eager run bit for bit."""
+    from fly_bproject_amd.ppo import PPO
+    res = {}
+    for persistent in (False, True):
+        torch.manual_seed(0)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            agent = PPO(make_args(4096, persistent_rollout=persistent))
+            T = agent.rollout_size                      # 160: the prints at run_step 100, 200, 300 fall inside rollouts
+            for _ in range(2 * T + 37):
+                agent.run()
+        torch.cuda.synchronize()
+        assert agent.optim_step == 150
+        res[persistent] = (agent._obs_ring[:38].clone(), agent.all_acts[:37].clone(), agent.all_reward[:37].clone(),
+                           agent.all_log_prob[:37].clone(), agent._v_ring[:37].clone(), float(agent.action_var[0]),
+                           agent.policy.P.clone(), agent.policy.exp_avg_sq.clone(), agent.all_advantage.clone(),
+                           [ln for ln in buf.getvalue().splitlines() if ln.startswith("Steps:")])
+        agent.exit()
+    assert abs(res[False][5] - (0.2 - (2 * 160 + 37) * 1e-5)) < 1e-6
+    for i, (a, b) in enumerate(zip(res[False], res[True])):
+        if torch.is_tensor(a):
+            assert torch.equal(a, b), i
+        else:
+            assert a == b, (i, a, b)
+
+
+@pytest.mark.parametrize("gemm", GEMMS)
 @pytest.mark.parametrize("n", [33, 8192])
-def test_fused_forward_sample_matches_separate_kernels(n):
-    """mlp_forward_sample (policy + sampling in one launch) == mlp_forward then ppo_sample_logprob;
-    actions also bit-exact against the oracle's restatement of ppo.py:215-220."""
+def test_fused_forward_sample_matches_separate_kernels(n, gemm):
+    """mlp_forward_sample (policy + sampling in one launch) == mlp_forward then ppo_sample_logprob (the kernel
+    tests/test_hip_parity.py pins to g5); actions also bit-exact against the oracle's restatement of ppo.py:215-220."""
     import ctypes as C
     from fly_bproject_amd import _lib
     from fly_bproject_amd.policy import PackedPolicy
@@ -182,6 +217,7 @@ def test_fused_forward_sample_matches_separate_kernels(n):
     torch.manual_seed(n)
     net = Net(73, 18).to("cuda:0")
     pol = PackedPolicy(net, "cuda:0")
+    pol.gemm = gemm
     lib = _lib.load()
     x = torch.randn(n, 73, device="cuda:0")
     eps = torch.randn(n, 18, device="cuda:0")
@@ -199,6 +235,40 @@ def test_fused_forward_sample_matches_separate_kernels(n):
     a_o, lp_o = O.sample_logprob(mu.cpu().numpy(), var.cpu().numpy(), eps.cpu().numpy())
     assert np.array_equal(act2.cpu().numpy(), a_o)
     np.testing.assert_allclose(lp2.cpu().numpy(), lp_o, rtol=2e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize("gemm", GEMMS)
+@pytest.mark.parametrize("tag", ["v02", "v001", "vmix"])
+def test_fused_forward_sample_vs_reference_goldens(golden, gemm, tag):
+    """The fused policy + sampling launch against the reference's OWN outputs: g4's weights and observations give g4's
+    Net.pi (ppo.py:30), g5's recorded eps / variance then give action = clip(pi + sqrt(var) eps) and its log-prob
+    (ppo.py:215-220) -- evaluated here in float64 numpy from the golden pi, compared at the suite's 2e-5."""
+    import ctypes as C
+    from fly_bproject_amd import _lib
+    from fly_bproject_amd.policy import PackedPolicy
+    from fly_bproject_amd.ppo import Net
+    g4, g5 = golden("g4_net"), golden("g5_sample")
+    net = Net(73, 18).to("cuda:0")
+    net.load_state_dict({k: torch.from_numpy(g4[k]) for k in g4.files if "." in k})
+    pol = PackedPolicy(net, "cuda:0")
+    pol.gemm = gemm
+    x = torch.from_numpy(g4["x"]).to("cuda:0")
+    n = x.shape[0]
+    eps, var = torch.from_numpy(g5[tag + "_eps"]).to("cuda:0"), torch.from_numpy(g5[tag + "_var"]).to("cuda:0")
+    act = torch.empty(n, 18, device="cuda:0"); lp = torch.empty(n, device="cuda:0"); mu = torch.empty(n, 18, device="cuda:0")
+    v = torch.empty(n, device="cuda:0")
+    p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    _lib.check(_lib.load().mlp_forward_sample(p(pol.P), p(pol.PF), p(x), n, p(eps), p(var), 0, 0.0, 0.0, p(act), p(lp), p(mu),
+                                              p(v), pol.infer_pb_ptr(), None, None), "fused")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(mu.cpu().numpy(), g4["pi"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(v.cpu().numpy(), g4["v"][:, 0], rtol=2e-5, atol=2e-5)
+    L = np.sqrt(g5[tag + "_var"].astype(np.float64))
+    a64 = g4["pi"].astype(np.float64) + L * g5[tag + "_eps"].astype(np.float64)
+    np.testing.assert_allclose(act.cpu().numpy(), np.clip(a64, -1, 1), rtol=2e-5, atol=2e-5)
+    # the log-prob is of the UNCLIPPED sample: -0.5 (18 log 2pi + |eps|^2) - sum log L  (mu cancels)
+    lp64 = -0.5 * (18 * np.log(2 * np.pi) + (g5[tag + "_eps"].astype(np.float64) ** 2).sum(1)) - np.log(L).sum()
+    np.testing.assert_allclose(lp.cpu().numpy(), lp64, rtol=2e-5, atol=2e-5)
 
 
 def test_trainer_entry_point(tmp_path, capsys):
