@@ -48,6 +48,12 @@ extern "C" hipError_t flyhip_p2p_alloc(int64_t n_floats, void** out);
 extern "C" hipError_t flyhip_launch_p2p_allreduce(float* G, int64_t n, void* const* bases, int rank, int world,
                                                   uint32_t epoch, int* err, int64_t fail_slot, void* stream);
 extern "C" int64_t flyhip_mlp_grad_workspace_floats(void);
+extern "C" int64_t flyhip_mlp_fused_workspace_floats(void);
+extern "C" hipError_t flyhip_launch_mlp_fused_grad(const float* P, const uint16_t* PB, const uint16_t* PTB, const float* x,
+                                                   int64_t n, const float* action, const float* old_logp, const float* adv,
+                                                   const float* target, const float* var, float inv_batch, float clip,
+                                                   float* workspace, float* grad_out, const float* norm_mask, float* norm_ws,
+                                                   int* norm_step, float* loss_part, float* const* dump, void* stream);
 extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, const float* h2, const float* h3,
                                                const float* dz1, const float* dz2, const float* dz3, const float* dz4,
                                                int64_t n, float* workspace, float* grad_out, const float* norm_mask,
@@ -158,7 +164,7 @@ int launch(FlyHandle h, int phases, const float* actions, const FlyBuffers* b, v
 extern "C" {
 
 const char* fly_last_error(void) { return g_err; }
-int fly_abi_version(void) { return 6; }
+int fly_abi_version(void) { return 7; }
 
 int fly_create(const FlyConfig* cfg, FlyHandle* out)
 {
@@ -395,6 +401,28 @@ int mlp_grad_w(const float* x, const float* h1_saved, const float* h2_saved, con
     hipError_t e = flyhip_launch_mlp_grad_w(x, h1_saved, h2_saved, h3_saved, dz1, dz2, dz3, dz4, n, workspace, grad, norm_mask,
                                             norm_ws, norm_step, err, gemm_b3, stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_grad_w launch");
+    return FLY_OK;
+}
+
+int64_t mlp_fused_workspace_floats(void) { return flyhip_mlp_fused_workspace_floats(); }
+
+int mlp_fused_grad(const float* params, const uint16_t* params_b3, const uint16_t* params_t_b3, const float* x, int64_t n,
+                   const float* action, const float* old_logp, const float* adv, const float* target, const float* var,
+                   float inv_batch, float clip, float* workspace, float* grad, const float* norm_mask, float* norm_ws,
+                   int32_t* norm_step, float* loss_part, float* const* debug_dump, void* stream)
+{
+    if ((norm_ws != nullptr) != (norm_mask != nullptr) || (norm_ws != nullptr) != (norm_step != nullptr))
+        return fail(FLY_E_ARG, "mlp_fused_grad: norm_mask, norm_ws and norm_step go together");
+    if (!params || !params_b3 || !params_t_b3) return fail(FLY_E_ARG, "mlp_fused_grad: needs params and both bf16x3 plane buffers");
+    if (!x || !action || !old_logp || !adv || !target || !var || !workspace || !grad)
+        return fail(FLY_E_ARG, "mlp_fused_grad: null pointer");
+    if (n <= 0) return fail(FLY_E_ARG, "mlp_fused_grad: n must be > 0");
+    if (debug_dump)
+        for (int i = 0; i < 8; ++i)
+            if (!debug_dump[i]) return fail(FLY_E_ARG, "mlp_fused_grad: debug_dump[%d] is null", i);
+    hipError_t e = flyhip_launch_mlp_fused_grad(params, params_b3, params_t_b3, x, n, action, old_logp, adv, target, var, inv_batch,
+                                                clip, workspace, grad, norm_mask, norm_ws, norm_step, loss_part, debug_dump, stream);
+    if (e != hipSuccess) return hip_fail(e, "mlp_fused_grad launch");
     return FLY_OK;
 }
 

@@ -13,6 +13,8 @@
 //   mlp_backward.inc  PPO loss gradient + dX chain of a tile, and the ONE-launch forward+backward
 //                     kernel whose backward workgroups wait on per-tile flags of the forward ones
 //   mlp_grad_w.inc    dW = dZ^T A over row slabs (one partial per workgroup) + fixed-order reduction
+//   mlp_fused_step.inc  ONE persistent launch per minibatch: forward, loss, dX chain and dW of every tile in the workgroup
+//                     that owns it (bf16x3; activations never leave the CU, dW accumulated in registers)
 //   mlp_adam.inc      clip_grad_norm_ + Adam on the packed parameters
 //
 // The operand roles are fixed throughout: weights are the MFMA "A" operand, activations the "B"
@@ -32,6 +34,7 @@ namespace {
 #include "mlp_forward.inc"
 #include "mlp_backward.inc"
 #include "mlp_grad_w.inc"
+#include "mlp_fused_step.inc"
 #include "mlp_adam.inc"
 #include "fly_body.inc"
 
@@ -371,6 +374,74 @@ extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, 
 }
 
 extern "C" int flyhip_mlp_reduce_blocks(void) { return RED_BLOCKS; }
+
+// ---- the fused optimizer-step gradient: mlp_fused_step_kernel + the fixed-order reduction of its per-workgroup slabs ------
+static int g_fused_grid_override = 0;    // test / tuning hook: fewer workgroups than CUs (each then walks more tiles)
+extern "C" void flyhip_debug_set_fused_grid(int grid) { g_fused_grid_override = grid; }
+static int fused_cus()
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
+    }
+    return cus;
+}
+static int fused_grid(int64_t n)
+{
+    int g = fused_cus();
+    if (g_fused_grid_override > 0 && g_fused_grid_override < g) g = g_fused_grid_override;
+    const long tiles = (n + BM - 1) / BM;
+    return (int)(tiles < g ? tiles : g);
+}
+
+extern "C" int64_t flyhip_mlp_fused_workspace_floats(void)
+{
+    return (int64_t)fused_cus() * MLP_PACKED_FLOATS;            // one partial slab per workgroup
+}
+
+extern "C" hipError_t flyhip_launch_mlp_fused_grad(const float* P, const uint16_t* PB, const uint16_t* PTB, const float* x,
+                                                   int64_t n, const float* action, const float* old_logp, const float* adv,
+                                                   const float* target, const float* var, float inv_batch, float clip,
+                                                   float* workspace, float* grad_out, const float* norm_mask, float* norm_ws,
+                                                   int* norm_step, float* loss_part, float* const* dump, void* stream)
+{
+    const int grid = fused_grid(n);
+    static bool attr_set[2] = {false, false};
+    FusedDump d = {};
+    const bool dbg = dump != nullptr;
+    if (dbg) { d.out = dump[0]; d.h1 = dump[1]; d.h2 = dump[2]; d.h3 = dump[3]; d.dz4 = dump[4]; d.dz3 = dump[5]; d.dz2 = dump[6]; d.dz1 = dump[7]; }
+    if (!attr_set[dbg]) {
+        hipError_t ea = dbg ? hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_step_kernel<true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, FS_LDS_BYTES)
+                            : hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_step_kernel<false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, FS_LDS_BYTES);
+        if (ea != hipSuccess) return ea;
+        attr_set[dbg] = true;
+    }
+    if (dbg)
+        hipLaunchKernelGGL(mlp_fused_step_kernel<true>, dim3(grid), dim3(THREADS), FS_LDS_BYTES, (hipStream_t)stream, P, PB, PTB, x,
+                           (long)n, action, old_logp, adv, target, var, inv_batch, clip, workspace, loss_part, d);
+    else
+        hipLaunchKernelGGL(mlp_fused_step_kernel<false>, dim3(grid), dim3(THREADS), FS_LDS_BYTES, (hipStream_t)stream, P, PB, PTB, x,
+                           (long)n, action, old_logp, adv, target, var, inv_batch, clip, workspace, loss_part, d);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // the slabs have the layout the reduction already sums: per layer `grid` blocks of N*KP + N floats
+    GradWTable T;
+    const int N[4] = {MLP_H1, MLP_H2, MLP_H3, MLP_OUT};
+    const int KP[4] = {MLP_IN_PAD, MLP_H1, MLP_H2, MLP_H3};
+    float* w = workspace;
+    for (int l = 0; l < 4; ++l) {
+        T.l[l].dz = nullptr; T.l[l].a = nullptr; T.l[l].partial = w;
+        T.l[l].N = N[l]; T.l[l].Ka = KP[l]; T.l[l].KP = KP[l]; T.l[l].wgs = grid; T.l[l].first_block = 0; T.l[l].accumulate = 0;
+        w += (long)grid * ((long)N[l] * KP[l] + N[l]);
+    }
+    hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3(RED_BLOCKS), dim3(64 * RED_WAVES), 0, (hipStream_t)stream, T, grad_out,
+                       norm_mask, norm_ws, norm_step, (const int*)nullptr);
+    return hipGetLastError();
+}
 
 extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PF, float* PT, const int* idx_f, const int* idx_t,
                                              const float* G, const float* mask, float* m,

@@ -277,6 +277,11 @@ class PackedPolicy:
         self._tile_flags = torch.zeros((r + 31) // 32, dtype=torch.int32, device=dev)
         self.tile_wait_error = torch.zeros(1, dtype=torch.int32, device=dev)
         self._epoch = 0
+        # bf16x3 only: the whole minibatch gradient in ONE persistent launch (csrc/mlp_fused_step.inc: forward, loss, dX chain and
+        # dW of a tile in the workgroup that owns it; nothing but x, the per-row scalars and one partial slab per CU touches
+        # HBM).  FLY_FUSED_STEP=0 keeps the three-launch path (the A/B).
+        self.fused_step = os.environ.get("FLY_FUSED_STEP", "1") != "0"
+        self._fused_ws = None
         self.fuse_fwd_bwd = os.environ.get("FLY_FUSE_FWD_BWD", "1") != "0"
         # how a tile travels from its forward to its backward workgroup inside the one launch
         # (csrc/mlp_backward.inc): "sc1" = write-through stores + L1-bypassing loads, no placement
@@ -307,7 +312,7 @@ class PackedPolicy:
             self.tile_wait_error.zero_()
         return err
 
-    def minibatch_grad(self, x, action, old_logp, adv, target, var, clip, global_rows=None, fuse_norm=False):
+    def minibatch_grad(self, x, action, old_logp, adv, target, var, clip, global_rows=None, fuse_norm=False, dump=False):
         """Forward + loss + backward of one minibatch; leaves the packed gradient in `self.G`.
         `fuse_norm` (single rank): the partial reduction also prepares the clip norm and advances the
         step, so `adam_step(norm_ready=True)` is one launch."""
@@ -319,6 +324,10 @@ class PackedPolicy:
         p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
         st = _lib.stream_ptr()
         inv_b = 1.0 / float(global_rows if global_rows else n)
+        if self.fused_step and self.gemm == "bf16x3":
+            return self._fused_grad(x, action, old_logp, adv, target, var, clip, inv_b, fuse_norm, dump)
+        if dump:
+            raise ValueError("dump=True is a debugging aid of the fused step")
         if self.fuse_fwd_bwd:
             # one launch: the backward workgroup of a row tile starts when that tile's forward is done
             if self._epoch >= (1 << 27) - 1:
@@ -344,8 +353,27 @@ class PackedPolicy:
                                         p(self.tile_wait_error), C.c_int(1 if self.gemm == "bf16x3" else 0), st),
                    "mlp_grad_w")
 
+    def _fused_grad(self, x, action, old_logp, adv, target, var, clip, inv_b, fuse_norm, dump):
+        """`mlp_fused_grad`: one persistent launch + the slab reduction.  dump=True (tests) also writes the chain's values into
+        self.saves / self.dz exactly as the three-launch path leaves them."""
+        n = x.shape[0]
+        p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+        if self._fused_ws is None:
+            self._fused_ws = torch.empty(int(self._lib.mlp_fused_workspace_floats()), device=self.device)
+        nm = (p(self.grad_mask), p(self._norm_ws), p(self.step)) if fuse_norm else (None, None, None)
+        dptr = None
+        if dump:
+            s, d = self.saves, self.dz
+            arr = (C.c_void_p * 8)(*[t.data_ptr() for t in (s["out"], s["h1"], s["h2"], s["h3"], d["dz4"], d["dz3"], d["dz2"], d["dz1"])])
+            dptr = arr
+        _lib.check(self._lib.mlp_fused_grad(p(self.P), p(self.PB), p(self.PTB), p(x), C.c_int64(n), p(action), p(old_logp), p(adv),
+                                            p(target), p(var), C.c_float(inv_b), C.c_float(clip), p(self._fused_ws), p(self.G), *nm,
+                                            p(self.loss_part), dptr, _lib.stream_ptr()), "mlp_fused_grad")
+
     def update_path(self):
         """Which launches one optimizer step is made of (for the bench line)."""
+        if self.fused_step and self.gemm == "bf16x3":
+            return "mlp_fused_grad (ONE persistent launch: forward + loss + dX chain + dW per tile, slabs reduced) + mlp_adam_step, gemm=bf16x3"
         if self.fuse_fwd_bwd:
             return "mlp_forward_backward (one launch, per-tile flags) + mlp_grad_w (+reduce) + mlp_adam_step, gemm=" + self.gemm
         return "mlp_forward + mlp_backward_dx + mlp_grad_w (+reduce) + mlp_adam_step, gemm=" + self.gemm

@@ -338,6 +338,27 @@ int mlp_grad_w(const float* x, const float* h1_saved, const float* h2_saved, con
                const float* dz1, const float* dz2, const float* dz3, const float* dz4, int64_t n,
                float* workspace, float* grad, const float* norm_mask, float* norm_ws, int32_t* norm_step,
                const int32_t* err, int32_t gemm_b3, void* stream);
+
+/*
+ * The whole gradient of one PPO minibatch (ppo.py:184-197: net.pi / net.v on the minibatch, ratio, clipped surrogate,
+ * smooth_l1, loss.mean().backward()) in ONE persistent launch plus the fixed-order reduction: what
+ * mlp_forward_backward + mlp_grad_w compute, without handing activations or dZ through HBM.  One workgroup per CU
+ * walks 32-row tiles; a tile's forward, loss, dX chain and dW / db contributions all happen in that workgroup with
+ * the activations in LDS (bf16x3 term planes that serve the row reads of the forward / dX GEMMs and, through the
+ * transposing LDS read, the row-reducing dW GEMMs) and dW accumulated in registers across the workgroup's tiles;
+ * each workgroup writes one partial slab (the packed-gradient layout) into `workspace`
+ * (mlp_fused_workspace_floats() floats), which the reduction sums into `grad`.  bf16x3 arithmetic only
+ * (params_b3 / params_t_b3 required; see mlp_forward).  norm_mask / norm_ws / norm_step as in mlp_grad_w (all
+ * three or none).  loss_part f32 [ceil(n/32)][2] as in mlp_backward_dx.  There is no cross-workgroup hand-off
+ * inside the launch, hence no err word.
+ * `debug_dump` (normally NULL): 8 device pointers {out, h1, h2, h3, dz4, dz3, dz2, dz1} sized and laid out like
+ * mlp_forward's saves / mlp_backward_dx's outputs; the launch then also writes the chain's values there (tests).
+ */
+int64_t mlp_fused_workspace_floats(void);
+int mlp_fused_grad(const float* params, const uint16_t* params_b3, const uint16_t* params_t_b3, const float* x, int64_t n,
+                   const float* action, const float* old_logp, const float* adv, const float* target, const float* var,
+                   float inv_batch, float clip, float* workspace, float* grad, const float* norm_mask, float* norm_ws,
+                   int32_t* norm_step, float* loss_part, float* const* debug_dump, void* stream);
 int mlp_adam_step(float* params, float* params_frag, float* params_t_frag, const int32_t* idx_frag,
                   const int32_t* idx_t_frag, const float* grad, const float* mask, float* exp_avg,
                   float* exp_avg_sq, int32_t* step, float lr, float beta1, float beta2, float eps,
