@@ -417,9 +417,12 @@ int mlp_fused_grad(const float* params, const uint16_t* params_b3, const uint16_
     if (!x || !action || !old_logp || !adv || !target || !var || !workspace || !grad)
         return fail(FLY_E_ARG, "mlp_fused_grad: null pointer");
     if (n <= 0) return fail(FLY_E_ARG, "mlp_fused_grad: n must be > 0");
-    if (debug_dump)
-        for (int i = 0; i < 8; ++i)
-            if (!debug_dump[i]) return fail(FLY_E_ARG, "mlp_fused_grad: debug_dump[%d] is null", i);
+    if (debug_dump) {
+        if (!debug_dump[0]) return fail(FLY_E_ARG, "mlp_fused_grad: debug_dump[0] is null");
+        if (debug_dump[1])      // the chain dump: all eight; {stamps, NULL}: the diagnostic stamp build (tools/stamp_fused.py)
+            for (int i = 2; i < 8; ++i)
+                if (!debug_dump[i]) return fail(FLY_E_ARG, "mlp_fused_grad: debug_dump[%d] is null", i);
+    }
     hipError_t e = flyhip_launch_mlp_fused_grad(params, params_b3, params_t_b3, x, n, action, old_logp, adv, target, var, inv_batch,
                                                 clip, workspace, grad, norm_mask, norm_ws, norm_step, loss_part, debug_dump, stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_fused_grad launch");

@@ -408,24 +408,25 @@ extern "C" hipError_t flyhip_launch_mlp_fused_grad(const float* P, const uint16_
                                                    int* norm_step, float* loss_part, float* const* dump, void* stream)
 {
     const int grid = fused_grid(n);
-    static bool attr_set[2] = {false, false};
+    static bool attr_set[3] = {false, false, false};
     FusedDump d = {};
-    const bool dbg = dump != nullptr;
-    if (dbg) { d.out = dump[0]; d.h1 = dump[1]; d.h2 = dump[2]; d.h3 = dump[3]; d.dz4 = dump[4]; d.dz3 = dump[5]; d.dz2 = dump[6]; d.dz1 = dump[7]; }
-    if (!attr_set[dbg]) {
-        hipError_t ea = dbg ? hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_step_kernel<true>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, FS_LDS_BYTES)
-                            : hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_step_kernel<false>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, FS_LDS_BYTES);
+    // debug_dump: 8 pointers = the chain dump (tests); ONE pointer followed by NULL = a stamp buffer (tools/stamp_fused.py)
+    const int mode = dump == nullptr ? 0 : (dump[1] == nullptr ? 2 : 1);
+    if (mode == 1) { d.out = dump[0]; d.h1 = dump[1]; d.h2 = dump[2]; d.h3 = dump[3]; d.dz4 = dump[4]; d.dz3 = dump[5]; d.dz2 = dump[6]; d.dz1 = dump[7]; }
+    if (mode == 2) d.out = dump[0];
+    const void* fn = mode == 0 ? reinterpret_cast<const void*>(mlp_fused_step_kernel<0>)
+                   : mode == 1 ? reinterpret_cast<const void*>(mlp_fused_step_kernel<1>)
+                               : reinterpret_cast<const void*>(mlp_fused_step_kernel<2>);
+    if (!attr_set[mode]) {
+        hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, FS_LDS_BYTES);
         if (ea != hipSuccess) return ea;
-        attr_set[dbg] = true;
+        attr_set[mode] = true;
     }
-    if (dbg)
-        hipLaunchKernelGGL(mlp_fused_step_kernel<true>, dim3(grid), dim3(THREADS), FS_LDS_BYTES, (hipStream_t)stream, P, PB, PTB, x,
-                           (long)n, action, old_logp, adv, target, var, inv_batch, clip, workspace, loss_part, d);
-    else
-        hipLaunchKernelGGL(mlp_fused_step_kernel<false>, dim3(grid), dim3(THREADS), FS_LDS_BYTES, (hipStream_t)stream, P, PB, PTB, x,
-                           (long)n, action, old_logp, adv, target, var, inv_batch, clip, workspace, loss_part, d);
+#define FS_LAUNCH(M_)                                                                                                             \
+    hipLaunchKernelGGL(mlp_fused_step_kernel<M_>, dim3(grid), dim3(THREADS), FS_LDS_BYTES, (hipStream_t)stream, P, PB, PTB, x,     \
+                       (long)n, action, old_logp, adv, target, var, inv_batch, clip, workspace, loss_part, d)
+    if (mode == 0) FS_LAUNCH(0); else if (mode == 1) FS_LAUNCH(1); else FS_LAUNCH(2);
+#undef FS_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // the slabs have the layout the reduction already sums: per layer `grid` blocks of N*KP + N floats
