@@ -55,6 +55,10 @@ gaps = np.array([s[b, t + 1, 0] - s[b, t, 11] for b in range(grid) for t in rang
 print("between tiles (stamp 11 of tile i -> stamp 0 of tile i+1): mean %.0f cycles" % gaps.mean())
 print("loop entry -> first tile's stamp 0: mean %.0f; last tile's stamp 11 -> loop exit: mean %.0f" %
       ((s[:, 0, 0] - s[:, 62, 2]).mean(), (s[:, 63, 0] - s[:, per - 1, 11]).mean()))
+sub = np.array([[s[b, t, 12] - s[b, t, 9], s[b, t, 13] - s[b, t, 12], s[b, t, 14] - s[b, t, 13], s[b, t, 15] - s[b, t, 14], s[b, t, 10] - s[b, t, 15]]
+                for b in range(grid) for t in range(per) if s[b, t, 11] > 0])
+print("inside P8: dW2 (96 MFMA) %.0f | dA1 GEMM + dz1 epilogue, tile 0 (48) %.0f | dW1 tile 0 (36) %.0f | GEMM + epilogue, tile 1 %.0f | dW1 tile 1 %.0f"
+      % tuple(sub.mean(0)))
 tail = s[:, 63, 1] - s[:, 63, 0]
 print("epilogue (slab write + bias sums) per workgroup: mean %.0f cycles" % tail.mean())
 pro = s[:, 62, 2] - s[:, 62, 0]
