@@ -280,7 +280,7 @@ class PackedPolicy:
         # bf16x3 only: the whole minibatch gradient in ONE persistent launch (csrc/mlp_fused_step.inc: forward, loss, dX chain and
         # dW of a tile in the workgroup that owns it; nothing but x, the per-row scalars and one partial slab per CU touches
         # HBM).  FLY_FUSED_STEP=0 keeps the three-launch path (the A/B).
-        self.fused_step = os.environ.get("FLY_FUSED_STEP", "0") != "0"
+        self.fused_step = os.environ.get("FLY_FUSED_STEP", "1") != "0"
         self._fused_ws = None
         self.fuse_fwd_bwd = os.environ.get("FLY_FUSE_FWD_BWD", "1") != "0"
         # how a tile travels from its forward to its backward workgroup inside the one launch
