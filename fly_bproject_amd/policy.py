@@ -127,9 +127,10 @@ class PackedPolicy:
         self.P = torch.zeros(PACKED, dtype=torch.float32, device=self.device)
         self.PF = torch.zeros(FRAG, dtype=torch.float32, device=self.device)      # forward operands, fragment order
         self.PT = torch.zeros(FRAG_T, dtype=torch.float32, device=self.device)    # W^T operands, fragment order
-        # GEMM arithmetic of the MFMA kernels: "f32" = v_mfma_f32_32x32x2_f32, "bf16x3" = three-term bf16
-        # split of both operands on v_mfma_f32_32x32x16_bf16 (fp32-accurate, see csrc/mlp_layout.h)
-        self._gemm = os.environ.get("FLY_GEMM", "f32")
+        # GEMM arithmetic of the MFMA kernels: "bf16x3" (default) = three-term bf16 split of both fp32 operands on
+        # v_mfma_f32_32x32x16_bf16, fp32 accumulate (held to the reference's golden vectors at the fp32 tolerances and to fp64:
+        # tests/test_ppo_gpu.py, tests/test_mlp_train_gpu.py, csrc/mlp_layout.h); "f32" = v_mfma_f32_32x32x2_f32 (FLY_GEMM=f32)
+        self._gemm = os.environ.get("FLY_GEMM", "bf16x3")
         self.gemm_infer = os.environ.get("FLY_GEMM_INFER", self._gemm)
         assert self._gemm in ("f32", "bf16x3") and self.gemm_infer in ("f32", "bf16x3")
         self.PB = torch.zeros(PB_HALVES, dtype=torch.int16, device=self.device)

@@ -34,8 +34,7 @@ def _setup(n, seed, sd=None, gemm=None):
     ref.load_state_dict({k: v.clone() for k, v in net.state_dict().items()})
     pol = PackedPolicy(net, DEV)
     pol.init_training(max(n, 32))
-    if gemm is not None:
-        pol.gemm = gemm
+    pol.gemm = gemm if gemm is not None else "f32"      # tests that do not name an arithmetic were written for the fp32 MFMA kernels
     g = torch.Generator(device=DEV).manual_seed(seed)
     x = torch.randn(n, 73, device=DEV, generator=g)
     var = torch.full((18,), 0.15, device=DEV)
@@ -151,6 +150,7 @@ def test_ppo_hip_and_torch_updates_agree():
         torch.manual_seed(0)
         with contextlib.redirect_stdout(io.StringIO()):
             agent = PPO(make_args(4096, update_backend=backend))
+            agent.policy.gemm = "f32"
             init = {k: v.clone() for k, v in agent.net.state_dict().items()}
             with torch.no_grad():
                 probe = torch.randn(512, 73, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9))
@@ -271,6 +271,7 @@ def test_bf16x3_training_step_matches_fp32_path():
     from fly_bproject_amd.policy import split_bf16x3, untile
     n = 4099
     net, ref, pol, (x, action, old_logp, adv, target, var) = _setup(n, 21)
+    pol.fused_step = False            # this test is about the three-launch kernels (the fused step: tests/test_fused_step_gpu.py)
     res = {}
     for mode in ("f32", "bf16x3"):
         pol.gemm = mode
@@ -350,6 +351,7 @@ def test_failed_fused_launch_is_refused_on_the_device_and_redone():
             with contextlib.redirect_stdout(out):
                 agent = PPO(make_args(4096))
                 pol = agent.policy
+                pol.gemm = "f32"                      # the flag hand-off inside mlp_forward_backward is the fp32 / three-launch path's
                 assert pol.fuse_fwd_bwd and pol.handoff == "xcd"
                 for _ in range(agent.rollout_size - 1):
                     agent.run()
