@@ -211,6 +211,10 @@ def kernel_rooflines(num_envs, T, reps, gemm="f32"):
                                  p(act), p(olp), p(adv), p(tgt), p(var), 1.0 / rows, 0.2, p(d["dz4"]), p(d["dz3"]),
                                  p(d["dz2"]), p(d["dz1"]), p(pol.loss_part), p(flags), epoch[0], p(err), pol.pb_ptr(), pol.ptb_ptr(),
                                  coherent, _lib.stream_ptr())
+    fused = pol.fused_step and pol.gemm == "bf16x3"
+    t_fused = None
+    if fused:       # the loop's optimizer-step gradient: ONE persistent launch (forward + loss + dX chain + dW) + the slab reduction
+        t_fused = _time_launches(lambda: pol.minibatch_grad(x, act, olp, adv, tgt, var, 0.2, fuse_norm=True), reps)
     t_fb = _time_launches(lambda: fwd_bwd(1 if pol.handoff == "sc1" else 0), reps)
     # A/B of the tile hand-off inside the launch: sc1 write-through + L1-bypassing loads vs plain accesses on one XCD
     t_fb_alt = _time_launches(lambda: fwd_bwd(0 if pol.handoff == "sc1" else 1), reps)
@@ -252,7 +256,11 @@ def kernel_rooflines(num_envs, T, reps, gemm="f32"):
                 "algorithmic_per_launch": bytes_per_launch, "launches_per_iteration": per_iter,
                 "iteration_share_ms": round(dur * per_iter * 1e3, 3)}
 
-    def mfma(name, dur, flop_per_launch, per_iter, peak=PEAK_F32_MFMA_TFLOPS):
+    # bf16x3 mode: six bf16 MFMA terms per product, so the algorithmic-FLOP roofline of every MLP GEMM is the dense bf16 peak / 6
+    mlp_peak = PEAK_F32_MFMA_TFLOPS if pol.gemm == "f32" else round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)
+
+    def mfma(name, dur, flop_per_launch, per_iter, peak=None):
+        peak = mlp_peak if peak is None else peak
         ach = flop_per_launch / dur / 1e12
         return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 5), "traffic": None,
@@ -267,14 +275,18 @@ def kernel_rooflines(num_envs, T, reps, gemm="f32"):
         hbm("fly_kernel<63> (fly_step)", t_step, FUSED_STEP_BYTES_PER_ENV * num_envs, 0),
         # the update's forward + loss + dX chain of one 40 960-row minibatch is ONE launch
         # bf16x3 mode: six bf16 MFMA terms per product, so the algorithmic-FLOP roofline is the dense bf16 peak / 6
-        mfma("mlp_fwd_bwd_kernel", t_fb, (MLP_FWD_FLOP + MLP_BWD_DX_FLOP) * rows, 75,
-             PEAK_F32_MFMA_TFLOPS if pol.gemm == "f32" else round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)),
+        mfma("mlp_fwd_bwd_kernel", t_fb, (MLP_FWD_FLOP + MLP_BWD_DX_FLOP) * rows, 0 if fused else 75),
         # the forward body alone at num_envs rows: once per iteration for v(last next_obs)
         mfma("mlp_forward_kernel (policy + sample, %d rows)" % num_envs, t_pol, MLP_FWD_FLOP * num_envs, 1),
-        mfma("mlp_grad_w_kernel (+reduce)", t_gw, MLP_GRAD_W_FLOP * rows, 75),
+        mfma("mlp_grad_w_kernel (+reduce)", t_gw, MLP_GRAD_W_FLOP * rows, 0 if fused else 75),
         hbm("mlp_adam_apply_kernel (clip + Adam + fragment refresh)", t_adam, 74272 * 4 * 10, 75),
         hbm("ppo_td_gae_kernel (T=%d x %d envs)" % (T, num_envs), t_gae, 20 * Tn, 1),
     ]
+    if fused:
+        # algorithmic FLOP of the whole minibatch gradient (forward + dX chain + dW); share 0 entries above are the three-launch
+        # A/B path (FLY_FUSED_STEP=0), timed on the same data
+        ks.insert(0, mfma("mlp_fused_step_kernel (forward + loss + dX + dW, %d rows; + mlp_grad_reduce_kernel)" % rows, t_fused,
+                          (MLP_FWD_FLOP + MLP_BWD_DX_FLOP + MLP_GRAD_W_FLOP) * rows, 75))
     # the env kernel's REAL bound is vector-instruction issue, not HBM: instructions per wave (committed PMC pass,
     # profiles/*_valu.json) x 4 issue cycles at one wave per SIMD, against the measured launch
     try:
@@ -306,13 +318,20 @@ def kernel_rooflines(num_envs, T, reps, gemm="f32"):
              "mlp_fwd_bwd_kernel": ("mlp_fwd_bwd_kernel", 2 * ((rows + 31) // 32) * 256),
              "rollout_step_kernel (policy + sample + env step, %d envs)" % num_envs: ("rollout_step_kernel", ((num_envs + 31) // 32) * 256),
              "mlp_forward_kernel (policy + sample, %d rows)" % num_envs: ("mlp_forward_kernel", ((num_envs + 31) // 32) * 256),
-             "mlp_grad_w_kernel (+reduce)": ("mlp_grad_w_kernel", 256 * 1024)}
+             "mlp_grad_w_kernel (+reduce)": ("mlp_grad_w_b3_kernel" if pol.gemm == "bf16x3" else "mlp_grad_w_kernel", 256 * 1024)}
+    if fused:
+        grids[ks[0]["kernel"]] = ("mlp_fused_step_kernel", 256 * 256)
     for k in ks:
         key = grids.get(k["kernel"])
         if key:
             t = traffic.get("%s@%d" % key)
             if t:
                 k["traffic"] = t["hbm_bytes_per_launch"]
+                if key[0] == "mlp_fused_step_kernel":       # the entry times the reduction with it: add its bytes
+                    r = traffic.get("mlp_grad_reduce_kernel@%d" % (291 * 1024))
+                    if r:
+                        k["traffic"] += r["hbm_bytes_per_launch"]
+                        k["traffic_note"] = "fused launch + slab reduction"
     for k in ks:
         if k["kernel"] == "mlp_fwd_bwd_kernel":
             k["handoff"] = pol.handoff
