@@ -614,11 +614,12 @@ def main():
     iteration()
     fence()
     rollout_s = time.perf_counter() - r0
-    # labelled variant: the same rollout as ONE launch (ppo_rollout_all, opt-in `persistent_rollout`: the device then runs
-    # ahead of the host's step count inside a rollout, so it is not the default of the drop-in `run()`)
+    # labelled A/B: the same rollout with one launch per env step (`persistent_rollout=False`; the default is ONE launch per
+    # rollout, ppo_rollout_all, with per-step reset / progress rows)
     persist_s = None
+    was_persistent = agent.persistent_rollout
     try:
-        agent.persistent_rollout = True
+        agent.persistent_rollout = not was_persistent
         iteration()
         fence()
         p0 = time.perf_counter()
@@ -626,7 +627,7 @@ def main():
         fence()
         persist_s = time.perf_counter() - p0
     finally:
-        agent.persistent_rollout = False
+        agent.persistent_rollout = was_persistent
     agent.args.testing = False
     if world > 1:
         tt = torch.tensor([elapsed, rollout_s], device=dev, dtype=torch.float64)
@@ -692,7 +693,9 @@ def main():
                        "grad_exchange": "none (1 rank)" if world == 1 else
                        ("%s, one call per optimizer step (75 per iteration), 297 KB" % agent_exchange)},
             "rollout_only_env_steps_per_s": round(world * a.num_envs * T / rollout_s, 1),
-            "rollout_only_one_launch_per_rollout_env_steps_per_s": None if not persist_s else round(world * a.num_envs * T / persist_s, 1),
+            "rollout_launches": "one per rollout (ppo_rollout_all)" if was_persistent else "one per env step (ppo_rollout_step)",
+            ("rollout_only_one_launch_per_step_env_steps_per_s" if was_persistent else "rollout_only_one_launch_per_rollout_env_steps_per_s"):
+                None if not persist_s else round(world * a.num_envs * T / persist_s, 1),
             "params_finite": finite,
             "refused_steps": refused,                  # fused forward+backward launches whose optimizer steps were refused and redone
             "mean_episode_return": None if ep_cnt == 0 else round(ep_ret, 4),

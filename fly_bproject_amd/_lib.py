@@ -37,7 +37,7 @@ SYMBOLS = {
     "ppo_adv_apply": [_P, _L, _P, _F, _F, _P],
     "ppo_step_bookkeeping": [_P, _L, _P, _F, _P, _I, _F, _F, _P],
     "ppo_rollout_step": [_P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _P, _P],
-    "ppo_rollout_all": [_P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P, _P, _P],
+    "ppo_rollout_all": [_P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     "ppo_rollout_bookkeeping": [_P, _L, _L, _P, _P, _F, _P, _I, _F, _F, _P, _P],
     "mlp_forward": [_P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P],
     "mlp_forward_sample": [_P, _P, _P, _L, _P, _P, _I, _F, _F, _P, _P, _P, _P, _P, _P],

@@ -92,7 +92,7 @@ extern "C" hipError_t flyhip_launch_rollout_all(const FlyConfig* dcfg, const Fly
                                                 float* obs_ring, int64_t n, const float* eps_all, const float* var,
                                                 float var_decay, float var_min, float* act_all, float* logp_all, float* v_ring,
                                                 float* reward_all, int T, const int* rows_applied, const uint16_t* PB,
-                                                void* stream);
+                                                int64_t* reset_rows, int64_t* progress_rows, void* stream);
 extern "C" hipError_t flyhip_launch_rollout_bookkeeping(const float* reward, int64_t rows, int64_t n, float* terms,
                                                         float* score_acc, float score_scale, float* action_var, int nvar,
                                                         float var_decay, float var_min, int* rows_applied, void* stream);
@@ -224,8 +224,9 @@ int ppo_rollout_step(FlyHandle h, const FlyBuffers* b, const float* params, cons
 int ppo_rollout_all(FlyHandle h, const FlyBuffers* b, const float* params, const float* params_frag, float* obs_ring,
                     const float* eps_all, const float* var, float var_decay, float var_min, float* act_all,
                     float* logp_all, float* v_ring, float* reward_all, int32_t T, const int32_t* rows_applied,
-                    const uint16_t* params_b3, void* stream)
+                    const uint16_t* params_b3, int64_t* reset_rows, int64_t* progress_rows, void* stream)
 {
+    if ((reset_rows != nullptr) != (progress_rows != nullptr)) return fail(FLY_E_ARG, "ppo_rollout_all: reset_rows and progress_rows go together");
     if (!h) return fail(FLY_E_ARG, "handle is null");
     if (!params || !params_frag || !obs_ring || !eps_all || !var || !act_all || !logp_all || !v_ring || !reward_all)
         return fail(FLY_E_ARG, "ppo_rollout_all: null pointer");
@@ -237,7 +238,7 @@ int ppo_rollout_all(FlyHandle h, const FlyBuffers* b, const float* params, const
     if (rc) return rc;
     hipError_t e = flyhip_launch_rollout_all(h->dev, &bb, params, params_frag, obs_ring, h->host.num_envs, eps_all, var,
                                              var_decay, var_min, act_all, logp_all, v_ring, reward_all, T, rows_applied,
-                                             params_b3, stream);
+                                             params_b3, reset_rows, progress_rows, stream);
     if (e != hipSuccess) return hip_fail(e, "ppo_rollout_all launch");
     return FLY_OK;
 }

@@ -88,7 +88,8 @@ __global__ __launch_bounds__(THREADS, WPS) void rollout_all_kernel(
     const FlyConfig* __restrict__ c, FlyBuffers b, const float* __restrict__ P, const void* __restrict__ PF,
     float* __restrict__ obs_ring, long n, const float* __restrict__ eps_all, const float* __restrict__ var, float var_decay,
     float var_min, float* __restrict__ act_all, float* __restrict__ logp_all, float* __restrict__ v_ring,
-    float* __restrict__ reward_all, int T, const int* __restrict__ rows_applied)
+    float* __restrict__ reward_all, int T, const int* __restrict__ rows_applied, int64_t* __restrict__ reset_rows,
+    int64_t* __restrict__ progress_rows)
 {
     constexpr int ARENA = B3 ? RS_B3_LDS_FLOATS : RS_LDS_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[ARENA + 32];
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(THREADS, WPS) void rollout_all_kernel(
         float* act = act_all + (long)t * n * MLP_NACT;
         b.obs = obs_ring + (long)(t + 1) * n * FLY_NUM_OBS;
         b.reward = reward_all + (long)t * n;
+        if (reset_rows) { b.reset = reset_rows + (long)t * n; b.progress = progress_rows + (long)t * n; }   // fly.py:175-177, per step
         if (B3)
             forward_body_b3<false>(lds, blockIdx.x, 1L << 40, P, static_cast<const u16*>(PF), x, n, nullptr, v_ring + (long)t * n,
                                    nullptr, nullptr, nullptr, nullptr, eps_all + (long)t * n * MLP_NACT, varcur, act,
@@ -133,7 +135,7 @@ extern "C" hipError_t flyhip_launch_rollout_all(const FlyConfig* dcfg, const Fly
                                                 float* obs_ring, int64_t n, const float* eps_all, const float* var,
                                                 float var_decay, float var_min, float* act_all, float* logp_all, float* v_ring,
                                                 float* reward_all, int T, const int* rows_applied, const uint16_t* PB,
-                                                void* stream)
+                                                int64_t* reset_rows, int64_t* progress_rows, void* stream)
 {
     const dim3 grid((unsigned)((n + BM - 1) / BM));
     int cus = 256;
@@ -141,7 +143,8 @@ extern "C" hipError_t flyhip_launch_rollout_all(const FlyConfig* dcfg, const Fly
     const bool one_per_cu = (int)grid.x <= cus;
 #define RA_LAUNCH(B3_, WPS_, PF_)                                                                                                  \
     hipLaunchKernelGGL((rollout_all_kernel<B3_, WPS_>), grid, dim3(THREADS), 0, (hipStream_t)stream, dcfg, *b, P, (const void*)PF_, \
-                       obs_ring, (long)n, eps_all, var, var_decay, var_min, act_all, logp_all, v_ring, reward_all, T, rows_applied)
+                       obs_ring, (long)n, eps_all, var, var_decay, var_min, act_all, logp_all, v_ring, reward_all, T, rows_applied, reset_rows, \
+                       progress_rows)
     if (PB) { if (one_per_cu) RA_LAUNCH(true, 1, PB); else RA_LAUNCH(true, 1, PB); }      // the bf16x3 body needs one wave per SIMD anyway
     else { if (one_per_cu) RA_LAUNCH(false, 1, PF); else RA_LAUNCH(false, 2, PF); }
 #undef RA_LAUNCH

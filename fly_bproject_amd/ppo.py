@@ -110,9 +110,18 @@ class PPO:
         self.normalize_advantage = bool(getattr(args, "normalize_advantage", False))
         self._adv_stats = torch.zeros(514, device=dev)
         self.use_graph = bool(getattr(args, "graph", False))
-        # one launch per ROLLOUT (ppo_rollout_all): each workgroup loops over the T steps of its own 32 envs.  Like
-        # graph=True the device then runs ahead of the host's step count inside a rollout.
-        self.persistent_rollout = bool(getattr(args, "persistent_rollout", False))
+        # one launch per ROLLOUT (ppo_rollout_all): each workgroup loops over the T steps of its own 32 envs.  The device then
+        # runs ahead of the host's step count inside a rollout, but everything `run()` reads per step is a ROW the launch wrote
+        # for that step: observation / reward / action / log-prob rows as always, and `env.reset_buf` / `env.progress_buf`
+        # (fly.py:175-177) are re-pointed at row t of per-step [T, N] tensors -- so it is the default whenever one launch stays
+        # short (T <= 4096 steps; the reference's 16-env shape, T = 40 960, steps launch by launch).  `persistent_rollout=False`
+        # (or FLY_PERSISTENT_ROLLOUT=0) keeps one launch per step; the env's STATE tensors (root_tensor, dof_states, ...) show the
+        # rollout's end while the host is still counting through it.
+        want = getattr(args, "persistent_rollout", None)
+        if want is None:
+            want = os.environ.get("FLY_PERSISTENT_ROLLOUT", "1") != "0"
+        self.persistent_rollout = bool(want) and T <= 4096 and not bool(getattr(args, "graph", False))
+        self._reset_rows = self._progress_rows = None
         self._graphs = {}
         self._fwd_args = None
         self._score_acc = torch.zeros((), device=dev)
@@ -193,6 +202,11 @@ class PPO:
         if getattr(self, "_action_var", None) is None:
             self._action_var = value
             return
+        if getattr(self, "persistent_rollout", False) and 0 < getattr(self, "_rows_done", 0) < self.rollout_size:
+            # one launch per rollout: the steps of the rollout in progress have already been sampled on the device
+            import warnings
+            warnings.warn("action_var assigned inside a rollout that was launched as ONE kernel: the new value takes effect at the "
+                          "next rollout (PPO(..., persistent_rollout=False) launches step by step and applies it at once)")
         if getattr(self, "_book_terms", None) is not None:
             self._flush_bookkeeping()
         with torch.no_grad():
@@ -477,12 +491,18 @@ class PPO:
         pol, env, T = self.policy, self.env, self.rollout_size
         self._eps_all.normal_(generator=self._gen)
         self._rows_applied.zero_()
+        if self._reset_rows is None:
+            n = int(self.args.num_envs)
+            self._reset_rows = torch.zeros((T, n), dtype=torch.long, device=self.device)
+            self._progress_rows = torch.zeros((T, n), dtype=torch.long, device=self.device)
+        # env._bufs.reset / .progress point at the CURRENT flags (the env's own tensors, or the last row of the previous
+        # rollout): the launch reads them once, then writes step t's flags to row t
         _lib.check(self._lib.ppo_rollout_all(
             env._handle, C.byref(env._bufs), P(pol.P.data_ptr()), P(pol.PF.data_ptr()), P(self._obs_ring.data_ptr()),
             P(self._eps_all.data_ptr()), P(self._action_var.data_ptr()), C.c_float(self._var_decay), self._var_min,
             P(self.all_acts.data_ptr()), P(self.all_log_prob.data_ptr()), P(self._v_ring.data_ptr()),
             P(self.all_reward.data_ptr()), C.c_int(T), P(self._rows_applied.data_ptr()), pol.infer_pb_ptr(),
-            _lib.stream_ptr()), "ppo_rollout_all")
+            P(self._reset_rows.data_ptr()), P(self._progress_rows.data_ptr()), _lib.stream_ptr()), "ppo_rollout_all")
 
     def _after_step(self, t):
         """Host-side state of a step that has been issued (launched or replayed): rows whose score / variance
@@ -507,10 +527,13 @@ class PPO:
             if self.persistent_rollout:
                 if t == 0:
                     self._launch_rollout()
-                self.env.obs_buf, self.env.reward_buf = self._obs_rows[t + 1], self._reward_rows[t]
-                self.env._bufs.obs, self.env._bufs.reward = self._buf_ptrs[t]
+                env = self.env
+                env.obs_buf, env.reward_buf = self._obs_rows[t + 1], self._reward_rows[t]
+                env._bufs.obs, env._bufs.reward = self._buf_ptrs[t]
+                env.reset_buf, env.progress_buf = self._reset_rows[t], self._progress_rows[t]      # this step's flags (fly.py:175-177)
+                env._bufs.reset, env._bufs.progress = env.reset_buf.data_ptr(), env.progress_buf.data_ptr()
                 self._after_step(t)
-                self.env.render_count += 1
+                env.render_count += 1
             elif not self.use_graph or self.run_step < self.rollout_size:
                 self._launch_step(t)
             else:

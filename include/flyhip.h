@@ -259,11 +259,13 @@ int ppo_rollout_step(FlyHandle h, const FlyBuffers* b, const float* params, cons
  * are ignored).  Envs of a 32-env tile depend on no other tile and the policy is constant inside a rollout, so each
  * workgroup runs its own tile's T steps.  Row t decays the variance (t - *rows_applied) times (rows_applied optional).
  * Bit for bit what T calls of ppo_rollout_step leave.  The launch runs for T x (one step's time): keep T <= a few
- * thousand. */
+ * thousand.  reset_rows / progress_rows (both or neither, int64 [T][N]): step t writes its reset / progress flags to row t
+ * instead of b->reset / b->progress (which are then only READ, once, at the start), so that a host that walks the rollout
+ * step by step after the launch finds the per-step buffers of fly.py:175-177 at row t. */
 int ppo_rollout_all(FlyHandle h, const FlyBuffers* b, const float* params, const float* params_frag, float* obs_ring,
                     const float* eps_all, const float* var, float var_decay, float var_min, float* act_all,
                     float* logp_all, float* v_ring, float* reward_all, int32_t T, const int32_t* rows_applied,
-                    const uint16_t* params_b3, void* stream);
+                    const uint16_t* params_b3, int64_t* reset_rows, int64_t* progress_rows, void* stream);
 
 
 /*

@@ -59,6 +59,10 @@ def test_action_var_schedule_and_done_mask():
     np.testing.assert_allclose(float(agent.action_var[0]), 0.2 - 7e-5, rtol=1e-5)   # ppo.py:237
     assert agent.all_done.shape == (4096, 1)                              # Q1: replaced by the last step's mask
     assert torch.equal(agent.all_done[:, 0], 1 - agent.env.reset_buf)
+    # the default is ONE launch per rollout: the device has run all 160 steps, but what run() exposes per step are that step's
+    # rows -- env.reset_buf / progress_buf (fly.py:175-177) included
+    assert agent.persistent_rollout and agent.env.progress_buf.data_ptr() == agent._progress_rows[6].data_ptr()
+    assert int(agent.env.progress_buf.max()) == 7 and torch.equal(agent.env.obs_buf, agent._obs_ring[7])
     assert torch.equal(agent.all_obs[1], agent.all_next_obs[0])           # ring aliasing
     agent.exit()
 
@@ -122,7 +126,7 @@ def test_rollout_values_equal_the_critic_pass():
     for reuse in (True, False):
         torch.manual_seed(0)
         with contextlib.redirect_stdout(io.StringIO()):
-            agent = PPO(make_args(4096, reuse_rollout_values=reuse))
+            agent = PPO(make_args(4096, reuse_rollout_values=reuse, persistent_rollout=False))   # steps launched one by one below
             _run(agent, agent.rollout_size - 1)
             agent._launch_step(agent.rollout_size - 1)           # last step without the update
         assert agent._v_have == (agent.rollout_size)
@@ -367,7 +371,7 @@ def test_one_launch_rollout_step_equals_two_launches(n):
     for fuse in (True, False):
         torch.manual_seed(0)
         with contextlib.redirect_stdout(io.StringIO()):
-            agent = PPO(make_args(n, testing=True))
+            agent = PPO(make_args(n, testing=True, persistent_rollout=False))     # one launch per STEP is what is compared here
             agent.run()
             assert agent.fuse_rollout_step
             agent.fuse_rollout_step = fuse
