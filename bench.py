@@ -38,13 +38,16 @@ def parse():
     ap.add_argument("--dp_allreduce", choices=["auto", "rccl", "p2p"], default="rccl",
                     help="per-optimizer-step gradient exchange of N > 1 ranks: rccl (default) = torch.distributed.all_reduce; "
                          "p2p = the one-shot peer-to-peer kernel; auto = p2p if its start-up self-test against RCCL passes on "
-                         "this node, else RCCL.  With rccl the p2p kernel is still opened, self-tested and TIMED as a labelled "
-                         "variant (`grad_exchange`), it just does not carry `value` until it has run on an xGMI node")
+                         "this node, else RCCL.  (--p2p_variant times the p2p kernel beside an rccl run.)")
     ap.add_argument("--gemm", choices=["bf16x3", "f32"], default=os.environ.get("FLY_GEMM", "bf16x3"),
                     help="arithmetic of every MLP GEMM of `value`: bf16x3 = fp32 operands split exactly into three bf16 terms, six "
                          "product terms on the bf16 matrix pipe, fp32 accumulate (held to the reference's golden vectors at the "
                          "fp32 tolerances: tests/test_mlp_train_gpu.py, tests/test_ppo_gpu.py); f32 = v_mfma_f32_32x32x2_f32.  The "
                          "other one is measured too and reported as the labelled secondary figure")
+    ap.add_argument("--p2p_variant", action="store_true",
+                    help="with --dp_allreduce rccl: also open, self-test and TIME the one-shot peer-to-peer exchange as a labelled "
+                         "variant (`grad_exchange_variants_us.p2p`).  Off by default: its cross-GPU leg has never run on xGMI "
+                         "hardware, and nothing optional should be able to take the scaling line down with it")
     ap.add_argument("--no_dqn", action="store_true", help="skip the short labelled DQN block (configs[4]) of the default line")
     ap.add_argument("--fail_rank", type=int, default=-1, help=argparse.SUPPRESS)     # test hook: that rank exits 3 at start
     ap.add_argument("--workload", choices=["ppo", "dqn"], default="ppo",
@@ -509,7 +512,7 @@ GEMM_LABEL = {
 }
 
 
-def time_exchange(agent, world, reps=50):
+def time_exchange(agent, world, reps=50, p2p_variant=False):
     """The per-optimizer-step gradient exchange ALONE (297 KB all-reduce of the packed gradient), timed with HIP events on
     the stream it is issued on; every rank runs it, the caller reports rank 0's figure.  Returns {variant: us per call}."""
     out = {}
@@ -533,7 +536,7 @@ def time_exchange(agent, world, reps=50):
     out["rccl"] = timed(lambda: dist.all_reduce(G, op=dist.ReduceOp.SUM))
     G.copy_(keep)
     p2p, own = agent._p2p, False
-    if p2p is None:                       # the labelled variant: open + self-test it now (collective; votes on every stage)
+    if p2p is None and p2p_variant:       # the labelled variant: open + self-test it now (collective; votes on every stage)
         try:
             want = agent.dp_allreduce
             agent.dp_allreduce = "auto"
@@ -634,7 +637,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, rollout_s = float(tt[0]), float(tt[1])
     assert steps_done == 75 * (a.warmup + a.steps), steps_done
-    exchange_us = time_exchange(agent, world)
+    exchange_us = time_exchange(agent, world, p2p_variant=a.p2p_variant)
     # Secondary, clearly labelled measurement: the same iteration with the OTHER arithmetic of the MLP GEMMs.
     alt = None
     main_gemm = agent.policy.gemm

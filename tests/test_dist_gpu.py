@@ -116,7 +116,7 @@ def test_bench_gpus_2_on_one_gpu():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-                        "--num_envs", "2048", "--no_cpu_baseline", "--no_alt_gemm", "--no_dqn", "--kernel_reps", "5"],
+                        "--num_envs", "2048", "--no_cpu_baseline", "--no_alt_gemm", "--no_dqn", "--p2p_variant", "--kernel_reps", "5"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -132,4 +132,5 @@ def test_bench_gpus_2_on_one_gpu():
     assert all(d["name"] and d["pid"] for d in cfg["devices"]) and cfg["devices"][0]["pid"] != cfg["devices"][1]["pid"]
     assert cfg["grad_exchange"].startswith("torch.distributed.all_reduce")
     assert line["grad_exchange_us_per_step"] > 0 and "rccl" in line["grad_exchange_variants_us"]
+    assert line["grad_exchange_variants_us"].get("p2p", 0) > 0 and line["p2p_selftest"] == "passed"      # --p2p_variant
     assert line["refused_steps"] == 0
