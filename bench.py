@@ -331,7 +331,7 @@ def kernel_rooflines(num_envs, T, reps, gemm="f32"):
             if t:
                 k["traffic"] = t["hbm_bytes_per_launch"]
                 if key[0] == "mlp_fused_step_kernel":       # the entry times the reduction with it: add its bytes
-                    r = traffic.get("mlp_grad_reduce_kernel@%d" % (291 * 1024))
+                    r = next((v for kk, v in sorted(traffic.items()) if kk.startswith("mlp_grad_reduce_kernel@")), None)
                     if r:
                         k["traffic"] += r["hbm_bytes_per_launch"]
                         k["traffic_note"] = "fused launch + slab reduction"
