@@ -57,7 +57,7 @@ print("loop entry -> first tile's stamp 0: mean %.0f; last tile's stamp 11 -> lo
       ((s[:, 0, 0] - s[:, 62, 2]).mean(), (s[:, 63, 0] - s[:, per - 1, 11]).mean()))
 sub = np.array([[s[b, t, 12] - s[b, t, 9], s[b, t, 13] - s[b, t, 12], s[b, t, 14] - s[b, t, 13], s[b, t, 15] - s[b, t, 14], s[b, t, 10] - s[b, t, 15]]
                 for b in range(grid) for t in range(per) if s[b, t, 11] > 0])
-print("inside P8: dW2 (96 MFMA) %.0f | dA1 GEMM + dz1 epilogue, tile 0 (48) %.0f | dW1 tile 0 (36) %.0f | GEMM + epilogue, tile 1 %.0f | dW1 tile 1 %.0f"
+print("inside P8: tile 0: dA1 GEMM (48 MFMA) %.0f | x DMA issue + dW2 with the dZ1 epilogue in its gaps (48) %.0f | dW1 tile 0 (36) %.0f | tile 1: GEMM + dW2/epilogue %.0f | dW1 tile 1 %.0f"
       % tuple(sub.mean(0)))
 tail = s[:, 63, 1] - s[:, 63, 0]
 print("epilogue (slab write + bias sums) per workgroup: mean %.0f cycles" % tail.mean())
