@@ -301,6 +301,14 @@ class PackedPolicy:
         self.minibatch_grad(z(n, IN), z(n, NACT), z(n), z(n), z(n), torch.full((NACT,), 0.2, device=self.device), 0.2)
         self.check_fused_launch()
 
+    def update_can_be_refused(self):
+        """True when a launch of the current update path can leave an invalid gradient that the optimizer kernels then refuse on
+        the device (the fused forward+backward launch's tile hand-off): the caller must read the step counter after the update
+        and redo what was refused.  The fused optimizer step (`mlp_fused_grad`) and the two-launch path cannot."""
+        if self.fused_step and self.gemm == "bf16x3":
+            return False
+        return bool(self.fuse_fwd_bwd)
+
     def check_fused_launch(self):
         """Host sync.  Returns the err word of the fused launches since the last check (0 = all fine) and
         clears it; a nonzero word switches this policy to the two-launch path.  The optimizer kernels

@@ -21,6 +21,7 @@ What changed underneath (MI355X-first, not a translation):
   * data-parallel training: one packed-gradient all-reduce over RCCL per optimizer step.
 """
 import ctypes as C
+import collections
 import os
 
 import torch
@@ -125,6 +126,18 @@ class PPO:
         self._graphs = {}
         self._fwd_args = None
         self._score_acc = torch.zeros((), device=dev)
+        # The reference prints its score line from a host read of device values (ppo.py:257-260).  A blocking read in the middle
+        # of a rollout that runs as ONE launch stalls the host until the launch ends, and the device then idles while the host
+        # walks the rest of the rollout's run() calls (measured: 150-270 us per iteration).  So log lines go through an ordered
+        # queue: a score line is an asynchronous copy into pinned memory plus an event, and lines are written, in order, as soon
+        # as the head of the queue is ready -- at the latest by flush_log() / exit() / the next blocking point.  The text and the
+        # order of the lines are the reference's; only the moment they appear moves.  `async_log=False` reads and prints at once.
+        want_async = getattr(args, "async_log", None)
+        if want_async is None:
+            want_async = os.environ.get("FLY_ASYNC_LOG", "1") != "0"
+        self._async_log = bool(want_async) and dev.type == "cuda"
+        self._log_q = collections.deque()
+        self._pending_step = None                                   # deferred check of the device step counter (_update_hip)
         self.env.bind_obs(self._obs_ring[0])                        # first policy input: zeros (Q8)
 
         self.score = 0
@@ -333,7 +346,21 @@ class PPO:
                 pol.adam_step(grad_scale=1.0 / self.world_size if sync_grads else 1.0, norm_ready=not sync_grads,
                               self_norm=sync_grads)       # either way ONE optimizer launch per step
 
+        self._check_step_counter()       # the previous update's counter, copied while this rollout ran
         run(slices)
+        if not pol.update_can_be_refused() and self._p2p is None and self._async_log:
+            # No launch of this update path can leave an invalid gradient (the fused optimizer step hands nothing from workgroup to
+            # workgroup), so the device counter only CONFIRMS the count: it is copied asynchronously and compared when the next
+            # update begins (or at exit) -- the host goes straight on to the next rollout instead of draining the queue here
+            # (measured: ~120 us of launch-bound idle per iteration behind a blocking read).
+            host = torch.empty(1, dtype=pol.step.dtype, pin_memory=True)
+            host.copy_(pol.step, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending_step = (ev, host, pol.steps_issued)
+            self.optim_step += len(slices)
+            self._finish_update(sync_grads)
+            return
         # ONE host sync per update.  A fused forward+backward launch whose backward could not get a tile
         # leaves an invalid gradient; the optimizer kernels refuse such a step ON THE DEVICE (on every
         # rank: the flag rides inside the all-reduced gradient), and every later step of this update too.
@@ -353,10 +380,16 @@ class PPO:
                   "could not get its tile); redoing them with two launches" % (short, len(slices)))
             run(slices[len(slices) - short:])
         self.optim_step += len(slices)
+        self._drain_log(block=True)                     # the queue is drained anyway: pending log lines cost nothing here
         if self._p2p is not None and not self._p2p.check():
             # fatal by design: this rank's optimizer refused the un-reduced gradients (fail closed), its peers cannot know
             raise _lib.FlyHipError("dp_allreduce_p2p: a rank never published its gradient (bounded wait expired; "
                                    "FLY_P2P_POLL_LOG2 raises the budget, --dp_allreduce rccl avoids the kernel)")
+        self._finish_update(sync_grads)
+
+    def _finish_update(self, sync_grads):
+        import torch.distributed as dist
+        pol = self.policy
         if self.world_size > 1 and not sync_grads:
             # dp_mode "param_average": ONE exchange per PPO update (BASELINE's north_star wording) --
             # ranks take their 75 optimizer steps locally, then parameters and Adam moments are
@@ -515,6 +548,65 @@ class PPO:
             self._v_have = t + 1
         self._rows_done = t + 1
 
+    SCORE_LINE = 'Steps: {:04d} | Opt Step: {:04d} | Reward {:.04f} | Action Var {:.04f}'
+
+    def _emit(self, text):
+        """A log line, behind whatever is still pending (see `_async_log`)."""
+        self._log_q.append(text)
+        self._drain_log()
+
+    def _emit_score(self):
+        """ppo.py:257-260: the score line of this step.  Values are read from the device asynchronously (pinned memory + event);
+        the accumulator is cleared on the stream, behind the copy."""
+        rank0 = int(getattr(self.args, "rank", 0)) == 0
+        if not self._async_log:
+            self._drain_log(block=True)
+            score = float(self._score_acc.item())
+            self._score_acc.zero_()
+            if rank0:
+                print(self.SCORE_LINE.format(self.run_step, self.optim_step, score, self._action_var[0].item()))
+            return
+        dev_vals = torch.stack((self._score_acc.reshape(()), self._action_var[0]))
+        host = torch.empty(2, dtype=torch.float32, pin_memory=True)
+        host.copy_(dev_vals, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._score_acc.zero_()
+        self._log_q.append((ev, host, dev_vals, self.run_step, self.optim_step, rank0))
+        self._drain_log()
+
+    def _drain_log(self, block=False):
+        """Write the queued lines whose values have arrived, in order; block=True waits for all of them."""
+        q = self._log_q
+        while q:
+            head = q[0]
+            if isinstance(head, str):
+                print(head)
+            else:
+                ev, host, _keep, run_step, optim_step, rank0 = head
+                if block:
+                    ev.synchronize()
+                elif not ev.query():
+                    return
+                if rank0:
+                    print(self.SCORE_LINE.format(run_step, optim_step, float(host[0]), float(host[1])))
+            q.popleft()
+
+    def flush_log(self):
+        """Blocks until every queued log line has been written (a host sync when one is pending)."""
+        self._drain_log(block=True)
+
+    def _check_step_counter(self):
+        """The deferred half of _update_hip's step check: the device counter copied at the end of the previous update."""
+        if self._pending_step is None:
+            return
+        ev, host, expect = self._pending_step
+        self._pending_step = None
+        ev.synchronize()
+        if int(host[0]) != expect:
+            raise _lib.FlyHipError("update: the device step counter says %d optimizer steps, %d were issued"
+                                   % (int(host[0]), expect))
+
     def run(self):
         """ppo.py:204-264: one env step of the rollout (and an update when the rollout is full).
         `graph=True` replays the device work of a whole rollout from ONE captured hipGraph (the first
@@ -564,27 +656,25 @@ class PPO:
         if t + 1 == self.rollout_size:                              # ppo.py:240-252
             self._flush_bookkeeping()                               # the update reads the decayed variance
             if not self.args.testing:
-                print("Training")
+                self._emit("Training")
                 self.update()
             self.mini_batch_number = 0
             with torch.no_grad():
                 self._obs_ring[0].copy_(self._obs_ring[self.rollout_size])
             self.env.bind_obs(self._obs_ring[0])
             if getattr(self.args, "save", False) and self.optim_step % self.args.save_freq == 0 and self.optim_step != 0:
-                print("saving...")
+                self._emit("saving...")
                 self.save(str(self.optim_step))
-                print("saved!")
+                self._emit("saved!")
         else:
             self.mini_batch_number += 1
 
         if self.run_step % self.num_eval_freq == 0:                 # ppo.py:257-260
             self._flush_bookkeeping()
-            self.score = float(self._score_acc.item())
-            self._score_acc.zero_()
-            if int(getattr(self.args, "rank", 0)) == 0:
-                print('Steps: {:04d} | Opt Step: {:04d} | Reward {:.04f} | Action Var {:.04f}'
-                      .format(self.run_step, self.optim_step, self.score, self._action_var[0].item()))
+            self._emit_score()
             self.score = 0
+        elif self._log_q:
+            self._drain_log()
 
         self.run_step += 1
         return end
@@ -593,6 +683,7 @@ class PPO:
         """ppo.py:266-273: state_dict only, reference key names."""
         if not getattr(self.args, "save", False):
             return
+        self._check_step_counter()
         if int(getattr(self.args, "rank", 0)) != 0:
             return
         path = self.args.save_path + endofname + ".pth"
@@ -603,6 +694,8 @@ class PPO:
         self.env.generate_video()
 
     def exit(self):
+        self._check_step_counter()
+        self.flush_log()
         if self._p2p is not None:
             self._p2p.close()
             self._p2p = None

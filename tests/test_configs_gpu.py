@@ -170,6 +170,7 @@ def test_log_txt_shape_300_envs():
         agent.action_var = torch.full((18,), 0.1, device="cuda:0")                  # the run in log.txt started at 0.1
         for _ in range(2201):
             agent.run()
+        agent.flush_log()                   # score lines are written when their values have arrived (PPO._emit_score)
     torch.cuda.synchronize()
     out = buf.getvalue().splitlines()
     assert "mini_chunk_size:  136" in out and "rollout_size:  2176" in out          # log.txt:24-25

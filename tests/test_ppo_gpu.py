@@ -193,6 +193,7 @@ def test_one_launch_per_rollout_in_training_mode():
             T = agent.rollout_size                      # 160: the prints at run_step 100, 200, 300 fall inside rollouts
             for _ in range(2 * T + 37):
                 agent.run()
+            agent.flush_log()
         torch.cuda.synchronize()
         assert agent.optim_step == 150
         res[persistent] = (agent._obs_ring[:38].clone(), agent.all_acts[:37].clone(), agent.all_reward[:37].clone(),
