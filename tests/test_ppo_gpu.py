@@ -384,3 +384,30 @@ def test_one_launch_rollout_step_equals_two_launches(n):
         agent.exit()
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)
+
+
+def test_asynchronous_log_queue_writes_the_same_lines_in_the_same_order():
+    """The score line (ppo.py:257-260) read asynchronously and written when its values have arrived (the default) against
+    read-and-print-at-once (`async_log=False`): the same stdout, line for line -- 'Training' and the score lines in the reference's
+    order --, and the same parameters after two updates; nothing is pending once flush_log() has returned, and a line queued by the
+    LAST run() call is not lost."""
+    from fly_bproject_amd.ppo import PPO
+    res = {}
+    for async_log in (False, True):
+        torch.manual_seed(0)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            agent = PPO(make_args(4096, async_log=async_log))
+            assert agent._async_log == async_log
+            T = agent.rollout_size                      # 160: score lines at run_step 0, 100, 200, 300 -- two of them inside rollouts
+            for _ in range(2 * T - 20 + 1):             # ends ON run_step 300: its line is queued by the last call
+                agent.run()
+            agent.flush_log()
+            assert not agent._log_q
+        torch.cuda.synchronize()
+        lines = [ln for ln in buf.getvalue().splitlines() if ln.startswith("Steps:") or ln == "Training"]
+        res[async_log] = (lines, agent.policy.P.clone(), agent.optim_step)
+        agent.exit()
+    assert res[True][0] == res[False][0] and len(res[True][0]) == 5 and res[True][0].count("Training") == 1
+    assert res[True][0][-1].startswith("Steps: 0300 | Opt Step: 0075")
+    assert res[True][2] == res[False][2] == 75 and torch.equal(res[True][1], res[False][1])
