@@ -92,39 +92,49 @@ __global__ __launch_bounds__(THREADS, WPS) void rollout_all_kernel(
     int64_t* __restrict__ progress_rows)
 {
     constexpr int ARENA = B3 ? RS_B3_LDS_FLOATS : RS_LDS_FLOATS;
-    __shared__ __attribute__((aligned(16))) float lds[ARENA + 32];
+    __shared__ __attribute__((aligned(16))) float lds[ARENA + 32 + BM * MLP_NACT];
     constexpr int PH_ALL = PH_SCALE | PH_RESET | PH_INTEGRATE | PH_OBS | PH_PROGRESS | PH_REWARD;
     // the variance of the CURRENT row lives in LDS and is decayed once per step (ppo.py:236-237): the same sequence of
     // fp32 operations as the per-step form, O(1) per step however long the rollout (T = 40 960 at 16 envs)
     float* varcur = lds + ARENA;
+    // bf16x3 body: the two hand-offs between the policy and the env step of a tile stay in LDS -- the sampled actions go to
+    // `acts` as well as to their HBM row, and the observation row the env step stages in the arena IS the next step's
+    // policy input -- so neither waits for its stores to be acknowledged nor reads its own row back through L2
+    // (the HBM rows are still written: the update reads them).  Same values, same bits.
+    float* acts = B3 ? lds + ARENA + 32 : nullptr;
     // the launch is the FIRST device work of its rollout: *rows_applied was zeroed just before it and no bookkeeping
     // flush can run until it has finished, so `var` is exactly the variance of row 0
     if (threadIdx.x < MLP_NACT) varcur[threadIdx.x] = var[threadIdx.x];
     FlyRegs st;
     fly_load<PH_ALL>(st, c, b, blockIdx.x);
     __syncthreads();
+    const bool whole = (long)(blockIdx.x + 1) * BM <= n;         // a ragged last tile keeps the HBM hand-offs (its LDS rows are partly stale)
     for (int t = 0; t < T; ++t) {
         const float* x = obs_ring + (long)t * n * FLY_NUM_OBS;
         float* act = act_all + (long)t * n * MLP_NACT;
         b.obs = obs_ring + (long)(t + 1) * n * FLY_NUM_OBS;
         b.reward = reward_all + (long)t * n;
         if (reset_rows) { b.reset = reset_rows + (long)t * n; b.progress = progress_rows + (long)t * n; }   // fly.py:175-177, per step
+        const bool in_lds = B3 && whole;
         if (B3)
             forward_body_b3<false>(lds, blockIdx.x, 1L << 40, P, static_cast<const u16*>(PF), x, n, nullptr, v_ring + (long)t * n,
                                    nullptr, nullptr, nullptr, nullptr, eps_all + (long)t * n * MLP_NACT, varcur, act,
-                                   logp_all + (long)t * n, nullptr, 0, var_decay, var_min);
+                                   logp_all + (long)t * n, nullptr, 0, var_decay, var_min,
+                                   in_lds && t > 0 ? lds : nullptr, in_lds ? acts : nullptr);
         else
             forward_body<false>(lds, blockIdx.x, 1L << 40, P, static_cast<const float*>(PF), x, n, nullptr, v_ring + (long)t * n,
                                 nullptr, nullptr, nullptr, nullptr, eps_all + (long)t * n * MLP_NACT, varcur, act,
                                 logp_all + (long)t * n, nullptr, 0, var_decay, var_min);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);          // this thread's action stores are acknowledged by L2
+        if (!in_lds) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);      // this thread's action stores are acknowledged by L2
+        }
         __syncthreads();
         FlyRegs nx;
-        fly_body<PH_ALL>(c, act, b, lds, blockIdx.x, st, &nx);
+        fly_body<PH_ALL>(c, act, b, lds, blockIdx.x, st, &nx, in_lds ? acts : nullptr);
         st = nx;
         if (threadIdx.x < MLP_NACT && var_decay > 0.0f) varcur[threadIdx.x] = fmaxf(var_min, varcur[threadIdx.x] - var_decay);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // observation row t + 1 is in L2 before any wave of this workgroup reads it
+        if (!in_lds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // observation row t + 1 is in L2 before any wave of this workgroup reads it
         __syncthreads();
     }
 }
