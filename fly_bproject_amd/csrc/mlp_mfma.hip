@@ -120,7 +120,7 @@ __global__ __launch_bounds__(THREADS, WPS) void rollout_all_kernel(
             forward_body_b3<false>(lds, blockIdx.x, 1L << 40, P, static_cast<const u16*>(PF), x, n, nullptr, v_ring + (long)t * n,
                                    nullptr, nullptr, nullptr, nullptr, eps_all + (long)t * n * MLP_NACT, varcur, act,
                                    logp_all + (long)t * n, nullptr, 0, var_decay, var_min,
-                                   in_lds && t > 0 ? lds : nullptr, in_lds ? acts : nullptr);
+                                   in_lds && t > 0 ? lds : nullptr, in_lds ? acts : nullptr, t > 0);
         else
             forward_body<false>(lds, blockIdx.x, 1L << 40, P, static_cast<const float*>(PF), x, n, nullptr, v_ring + (long)t * n,
                                 nullptr, nullptr, nullptr, nullptr, eps_all + (long)t * n * MLP_NACT, varcur, act,
