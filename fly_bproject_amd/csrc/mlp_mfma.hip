@@ -139,6 +139,38 @@ __global__ __launch_bounds__(THREADS, WPS) void rollout_all_kernel(
     }
 }
 
+// The same loop with the policy in the fused step's style (policy_tile_fs, mlp_fused_step.inc): swizzled plane images, the chain
+// GEMMs' asm MFMA streams, 135 KB of LDS -- one workgroup per CU, whole tiles only (the launcher checks both).  The env step
+// stages its observation block in H2's region of that image, which is where the next step's policy converts it from.
+__global__ __launch_bounds__(THREADS, 1) void rollout_all_fs_kernel(
+    const FlyConfig* __restrict__ c, FlyBuffers b, const float* __restrict__ P, const u16* __restrict__ PB,
+    float* __restrict__ obs_ring, long n, const float* __restrict__ eps_all, const float* __restrict__ var, float var_decay,
+    float var_min, float* __restrict__ act_all, float* __restrict__ logp_all, float* __restrict__ v_ring,
+    float* __restrict__ reward_all, int T, int64_t* __restrict__ reset_rows, int64_t* __restrict__ progress_rows)
+{
+    extern __shared__ __attribute__((aligned(16))) u16 fr_lds[];
+    const FrLds L(fr_lds);
+    constexpr int PH_ALL = PH_SCALE | PH_RESET | PH_INTEGRATE | PH_OBS | PH_PROGRESS | PH_REWARD;
+    if (threadIdx.x < 32) L.varcur[threadIdx.x] = threadIdx.x < MLP_NACT ? var[threadIdx.x] : 1.0f;   // the variance of row 0 (see rollout_all_kernel)
+    policy_tile_fs_setup(L, P);
+    FlyRegs st;
+    fly_load<PH_ALL>(st, c, b, blockIdx.x);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        float* act = act_all + (long)t * n * MLP_NACT;
+        b.obs = obs_ring + (long)(t + 1) * n * FLY_NUM_OBS;
+        b.reward = reward_all + (long)t * n;
+        if (reset_rows) { b.reset = reset_rows + (long)t * n; b.progress = progress_rows + (long)t * n; }   // fly.py:175-177, per step
+        policy_tile_fs(L, blockIdx.x, PB, t == 0 ? obs_ring : nullptr, n, v_ring + (long)t * n, eps_all + (long)t * n * MLP_NACT, act,
+                       logp_all + (long)t * n);
+        FlyRegs nx;
+        fly_body<PH_ALL>(c, act, b, L.obs, blockIdx.x, st, &nx, L.acts);
+        st = nx;
+        if (threadIdx.x < MLP_NACT && var_decay > 0.0f) L.varcur[threadIdx.x] = fmaxf(var_min, L.varcur[threadIdx.x] - var_decay);
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" hipError_t flyhip_launch_rollout_all(const FlyConfig* dcfg, const FlyBuffers* b, const float* P, const float* PF,
@@ -151,6 +183,19 @@ extern "C" hipError_t flyhip_launch_rollout_all(const FlyConfig* dcfg, const Fly
     int cus = 256;
     { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; }
     const bool one_per_cu = (int)grid.x <= cus;
+    static const bool fs_off = getenv("FLY_ROLLOUT_FS") != nullptr && getenv("FLY_ROLLOUT_FS")[0] == '0';
+    if (PB && one_per_cu && n % BM == 0 && !fs_off) {       // the policy body in the fused step's style (A/B: FLY_ROLLOUT_FS=0)
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_all_fs_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, FR_LDS_BYTES);
+            if (ea != hipSuccess) return ea;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(rollout_all_fs_kernel, grid, dim3(THREADS), FR_LDS_BYTES, (hipStream_t)stream, dcfg, *b, P, PB, obs_ring, (long)n,
+                           eps_all, var, var_decay, var_min, act_all, logp_all, v_ring, reward_all, T, reset_rows, progress_rows);
+        return hipGetLastError();
+    }
 #define RA_LAUNCH(B3_, WPS_, PF_)                                                                                                  \
     hipLaunchKernelGGL((rollout_all_kernel<B3_, WPS_>), grid, dim3(THREADS), 0, (hipStream_t)stream, dcfg, *b, P, (const void*)PF_, \
                        obs_ring, (long)n, eps_all, var, var_decay, var_min, act_all, logp_all, v_ring, reward_all, T, rows_applied, reset_rows, \
