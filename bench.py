@@ -179,6 +179,84 @@ MLP_GRAD_W_FLOP = MLP_FWD_FLOP
 PEAK_HBM_GBS, PEAK_F32_MFMA_TFLOPS, PEAK_BF16_MFMA_TFLOPS = 8000.0, 157.3, 2500.0                             # MI355X_MICROARCH.md
 
 
+PHYSICS_BYTES_PER_ENV = 464        # integrator alone, 4 * (2 * 49 state floats + 18 actions)
+
+
+class RolloutAllHarness:
+    """The loop's rollout launch (`ppo_rollout_all`, T env steps of every 32-env tile in ONE launch: rollout_all_fs_kernel at
+    8192 envs) on rollout tensors of its own, for HIP-event timing, for the profiler passes (tools/prof_kernels.py) and -- through
+    the stamped diagnostic instantiation -- for the policy / env split of a step."""
+
+    def __init__(self, env, pol, T, var):
+        import ctypes as C
+        from fly_bproject_amd import _lib
+        self.C, self._lib, self.lib = C, _lib, _lib.load()
+        self.env, self.pol, self.T, self.var = env, pol, T, var
+        n, dev = int(env.args.num_envs), "cuda:0"
+        self.n = n
+        self.obs_ring = torch.zeros(T + 1, n, 73, device=dev)
+        self.eps_all = torch.randn(T, n, 18, device=dev)
+        self.act_all = torch.empty(T, n, 18, device=dev)
+        self.logp_all = torch.empty(T, n, device=dev)
+        self.v_ring = torch.empty(T + 1, n, device=dev)
+        self.reward_all = torch.empty(T, n, device=dev)
+        self.reset_rows = torch.zeros(T, n, dtype=torch.long, device=dev)
+        self.progress_rows = torch.zeros(T, n, dtype=torch.long, device=dev)
+        self.rows_applied = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._first = True
+
+    def _args(self):
+        C = self.C
+        p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+        return (self.env._handle, C.byref(self.env._bufs), p(self.pol.P), p(self.pol.PF), p(self.obs_ring), p(self.eps_all),
+                p(self.var), C.c_float(0.00001), C.c_float(0.01), p(self.act_all), p(self.logp_all), p(self.v_ring),
+                p(self.reward_all), C.c_int(self.T))
+
+    def _chain(self):
+        # the next launch starts where this one ended: flags from the last row, the first observation = the last one written
+        if self._first:
+            self.env._bufs.reset = self.reset_rows[self.T - 1].data_ptr()
+            self.env._bufs.progress = self.progress_rows[self.T - 1].data_ptr()
+            self._first = False
+
+    def launch(self):
+        C = self.C
+        p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+        self._lib.check(self.lib.ppo_rollout_all(*self._args(), p(self.rows_applied), self.pol.infer_pb_ptr(), p(self.reset_rows),
+                                                 p(self.progress_rows), self._lib.stream_ptr()), "ppo_rollout_all")
+        self._chain()
+
+    def phase_split(self):
+        """Shader-clock stamps of every workgroup at the top of each step and between its policy and env halves (stamped
+        instantiation of rollout_all_fs_kernel): returns (policy share, env share) of a step, averaged over workgroups and
+        steps 1 .. T-1 (step 0 reads its rows from HBM).  None when the launch does not take the fused-style kernel."""
+        C = self.C
+        p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+        wgs = (self.n + 31) // 32
+        stamps = torch.zeros(wgs, self.T + 1, 2, dtype=torch.int64, device="cuda:0")
+        fn = self.lib.flyhip_debug_rollout_all_stamped
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p] + [C.c_void_p] * 5 + [C.c_float, C.c_float] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 5
+        rc = fn(self.env._handle, C.cast(C.byref(self.env._bufs), C.c_void_p), p(self.pol.P), p(self.pol.PF), p(self.obs_ring),
+                p(self.eps_all), p(self.var), 0.00001, 0.01, p(self.act_all), p(self.logp_all), p(self.v_ring), p(self.reward_all),
+                self.T, self.pol.infer_pb_ptr(), p(self.reset_rows), p(self.progress_rows), p(stamps), self._lib.stream_ptr())
+        if rc != 0:
+            return None
+        self._chain()
+        torch.cuda.synchronize()
+        s = stamps.cpu().numpy()
+        top, mid = s[:, :, 0], s[:, :-1, 1]
+        pol_c = (mid[:, 1:] - top[:, 1:-1]).astype("float64")
+        env_c = (top[:, 2:] - mid[:, 1:]).astype("float64")
+        tot = pol_c.mean() + env_c.mean()
+        return {"policy_frac": float(pol_c.mean() / tot), "env_frac": float(env_c.mean() / tot),
+                "policy_cycles": float(pol_c.mean()), "env_cycles": float(env_c.mean())}
+
+
+def mlp_peak_for(gemm):
+    return PEAK_F32_MFMA_TFLOPS if gemm == "f32" else round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)
+
+
 def kernel_rooflines(num_envs, T, reps, gemm="f32"):
     """Per-kernel roofline entries, each measured live with HIP events; the dominant kernel (largest
     share of one PPO iteration) is returned first."""
@@ -232,6 +310,16 @@ def kernel_rooflines(num_envs, T, reps, gemm="f32"):
     t_roll = _time_launches(lambda: lib.ppo_rollout_step(env._handle, C.byref(env._bufs), p(pol.P), p(pol.PF), p(xs), p(eps),
                                                          p(var), 0, 0.0, 0.0, p(a_o), p(lp_o), p(v_o), pol.infer_pb_ptr(),
                                                          None, _lib.stream_ptr()), reps)
+    # the loop's rollout: ONE launch for the T steps of every tile (rollout_all_fs_kernel at <= one tile per CU)
+    harness = RolloutAllHarness(env, pol, T, var)
+    t_all = _time_launches(harness.launch, max(3, reps // 20))
+    split = None
+    try:
+        harness.phase_split()
+        split = harness.phase_split()
+    except Exception:       # noqa: BLE001  (the split is a diagnostic: never cost the line)
+        split = None
+    del harness
     env.exit()
     t_gw = _time_launches(lambda: lib.mlp_grad_w(p(x), p(s["h1"]), p(s["h2"]), p(s["h3"]), p(d["dz1"]), p(d["dz2"]),
                                                  p(d["dz3"]), p(d["dz4"]), rows, p(pol.workspace), p(pol.G), None, None, None,
@@ -260,7 +348,7 @@ def kernel_rooflines(num_envs, T, reps, gemm="f32"):
                 "iteration_share_ms": round(dur * per_iter * 1e3, 3)}
 
     # bf16x3 mode: six bf16 MFMA terms per product, so the algorithmic-FLOP roofline of every MLP GEMM is the dense bf16 peak / 6
-    mlp_peak = PEAK_F32_MFMA_TFLOPS if pol.gemm == "f32" else round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)
+    mlp_peak = mlp_peak_for(pol.gemm)
 
     def mfma(name, dur, flop_per_launch, per_iter, peak=None):
         peak = mlp_peak if peak is None else peak
@@ -270,10 +358,34 @@ def kernel_rooflines(num_envs, T, reps, gemm="f32"):
                 "avg_launch_us": round(dur * 1e6, 3), "algorithmic_per_launch": flop_per_launch,
                 "launches_per_iteration": per_iter, "iteration_share_ms": round(dur * per_iter * 1e3, 3)}
 
+    fs_kernel = pol.gemm_infer == "bf16x3" and num_envs % 32 == 0 and num_envs // 32 <= torch.cuda.get_device_properties(0).multi_processor_count
+    roll_name = "%s (one launch per rollout: T=%d x [policy + sample + env step], %d envs)" % (
+        "rollout_all_fs_kernel" if fs_kernel else "rollout_all_kernel", T, num_envs)
+    roll_all = mfma(roll_name, t_all, MLP_FWD_FLOP * num_envs * T, 1)
+    roll_all["per_env_step_us"] = round(t_all / T * 1e6, 3)
+    if split:
+        # the north_star's physics kernel AS IT RUNS IN THE LOOP: the env half of a step (action scale, masked reset, 15 substeps,
+        # obs / reward / done pack) by in-kernel stamps, priced against the HBM roofline on SURVEY.md §8(d)'s byte counts
+        env_us = t_all / T * 1e6 * split["env_frac"]
+        pol_us = t_all / T * 1e6 * split["policy_frac"]
+        roll_all["phases"] = {
+            "source": "s_memtime stamps of the diagnostic instantiation (all workgroups, steps 1..T-1), shares applied to the HIP-event time",
+            "policy_us_per_step": round(pol_us, 3), "env_us_per_step": round(env_us, 3),
+            "policy_frac": round(split["policy_frac"], 4), "env_frac": round(split["env_frac"], 4),
+            "policy_mfma": {"achieved": round(MLP_FWD_FLOP * num_envs / pol_us / 1e6, 3), "peak": mlp_peak_for(pol.gemm),
+                            "unit": "TFLOP/s", "frac": round(MLP_FWD_FLOP * num_envs / pol_us / 1e6 / mlp_peak_for(pol.gemm), 5)},
+            "physics_in_loop": {
+                "bound": "hbm", "bytes_per_env_step": FUSED_STEP_BYTES_PER_ENV, "achieved": round(FUSED_STEP_BYTES_PER_ENV * num_envs / env_us / 1e3, 2),
+                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(FUSED_STEP_BYTES_PER_ENV * num_envs / env_us / 1e3 / PEAK_HBM_GBS, 5),
+                "integrator_only_bytes_per_env_step": PHYSICS_BYTES_PER_ENV,
+                "integrator_only_frac": round(PHYSICS_BYTES_PER_ENV * num_envs / env_us / 1e3 / PEAK_HBM_GBS, 5),
+                "note": "fused step K1-K5 (800 B per env-step) over the env half's time; the state never leaves registers between "
+                        "steps, so the bytes are the rows the loop writes/reads per step; the phase is VALU-issue-bound (valu_roofline)"}}
     ks = [
-        # the rollout's ONE launch per env step = policy forward + sampling + fused env step; priced as MFMA work
-        # (its forward half) -- the env half is VALU-issue-bound, see the stand-alone fly_kernel entry below
-        mfma("rollout_step_kernel (policy + sample + env step, %d envs)" % num_envs, t_roll, MLP_FWD_FLOP * num_envs, T),
+        roll_all,
+        # labelled A/B: ONE launch per env step (persistent_rollout=False) = policy forward + sampling + fused env step
+        mfma("rollout_step_kernel (A/B: one launch per env step; policy + sample + env step, %d envs)" % num_envs, t_roll,
+             MLP_FWD_FLOP * num_envs, 0),
         # north_star's physics kernel on its own (not launched by the default loop any more: share 0)
         hbm("fly_kernel<63> (fly_step)", t_step, FUSED_STEP_BYTES_PER_ENV * num_envs, 0),
         # the update's forward + loss + dX chain of one 40 960-row minibatch is ONE launch
@@ -305,6 +417,12 @@ def kernel_rooflines(num_envs, T, reps, gemm="f32"):
                     k["valu_roofline"] = {"bound": "valu-issue", "valu_insts_per_wave": ipw, "issue_cycles_per_inst": 4,
                                           "waves_per_simd": 1, "clock_ghz": clk, "floor_us": round(floor_us, 2),
                                           "frac": round(floor_us / (t_step * 1e6), 4), "source": os.path.basename(vf[-1])}
+                ph = k.get("phases")
+                if ph:      # the same body as the env half of a rollout step: its instruction count against the half's time
+                    ph["physics_in_loop"]["valu_roofline"] = {
+                        "bound": "valu-issue", "valu_insts_per_wave": ipw, "issue_cycles_per_inst": 4, "waves_per_simd": 1,
+                        "clock_ghz": clk, "floor_us": round(floor_us, 2), "frac": round(floor_us / ph["env_us_per_step"], 4),
+                        "source": os.path.basename(vf[-1])}
     except Exception:
         pass
     # HBM bytes per launch from the committed PMC passes (profiles/*_traffic.json, produced by
@@ -319,7 +437,8 @@ def kernel_rooflines(num_envs, T, reps, gemm="f32"):
         traffic = {}
     grids = {"fly_kernel<63> (fly_step)": ("fly_kernel<63>", ((num_envs + 31) // 32) * 256),
              "mlp_fwd_bwd_kernel": ("mlp_fwd_bwd_kernel", 2 * ((rows + 31) // 32) * 256),
-             "rollout_step_kernel (policy + sample + env step, %d envs)" % num_envs: ("rollout_step_kernel", ((num_envs + 31) // 32) * 256),
+             "rollout_step_kernel (A/B: one launch per env step; policy + sample + env step, %d envs)" % num_envs: ("rollout_step_kernel", ((num_envs + 31) // 32) * 256),
+             roll_name: ("rollout_all_fs_kernel" if fs_kernel else "rollout_all_kernel", ((num_envs + 31) // 32) * 256),
              "mlp_forward_kernel (policy + sample, %d rows)" % num_envs: ("mlp_forward_kernel", ((num_envs + 31) // 32) * 256),
              "mlp_grad_w_kernel (+reduce)": ("mlp_grad_w_b3_kernel" if pol.gemm == "bf16x3" else "mlp_grad_w_kernel", 256 * 1024)}
     if fused:
@@ -397,6 +516,65 @@ def cpu_baseline(num_envs):
                       "minibatch steps of 40960 samples + critic pass over %d rows, extrapolated to one "
                       "iteration (T=%d, 75 optimizer steps)" % (S, num_envs, M, 2 * mb, T),
             "rollout_env_steps_per_s": round(num_envs / t_step, 1)}
+
+
+def episode_return_vs_oracle(num_envs, steps=400):
+    """BASELINE's second metric, "mean episode return vs ref", as far as it can be had: the reference logs only the mean per-step
+    reward (ppo.py:233, :257-260) and its sim cannot run here, so the comparable is the ORACLE (part of the cpu_baseline leg)
+    on identical inputs -- the reference reset state (fly.py:446-480), the same initial weights (torch.manual_seed(0),
+    trainer.py:24), the same recorded eps, action_var 0.2 decaying 1e-5 per step (ppo.py:152, :236-237), `steps` env steps, no
+    update -- against the HIP env + MFMA policy.  Each side runs closed-loop on its OWN observations, so trajectories part
+    chaotically at the 1e-6 level and the comparison is STATISTICAL (mean return / length over the episodes that finish)."""
+    import numpy as np
+    from oracle import oracle as O
+    from oracle import ppo_oracle as PO
+    from fly_bproject_amd.fly import Fly
+    from fly_bproject_amd.policy import PackedPolicy
+    from fly_bproject_amd.ppo import Net
+    torch.manual_seed(0)
+    net = Net(73, 18)
+    onet = PO.OracleNet()
+    onet.load_state_dict({k: v.clone() for k, v in net.state_dict().items()})
+    net = net.to("cuda:0")
+    pol = PackedPolicy(net, "cuda:0")
+    env = Fly(make_args(num_envs))
+    cfg = O.default_config(num_envs)
+    s = O.EnvState(num_envs)
+    rng = np.random.default_rng(0)
+    var = np.float32(0.2)
+    obs_o = torch.zeros(num_envs, 73)
+    obs_h = torch.zeros(num_envs, 73, device="cuda:0")
+    ep_ret = np.zeros(num_envs); ep_len = np.zeros(num_envs)
+    done_ret, done_len, done_cnt = 0.0, 0.0, 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eps = rng.standard_normal((num_envs, 18)).astype(np.float32)
+        sd = np.float32(np.sqrt(var))
+        with torch.no_grad():
+            mu_o = onet.pi(obs_o).numpy()
+            mu_h = pol.forward(obs_h, want_mu=True, want_v=False)[0]
+        a_o = np.clip(mu_o + sd * eps, -1.0, 1.0).astype(np.float32)                 # ppo.py:218, :220
+        a_h = torch.clamp(mu_h + float(sd) * torch.from_numpy(eps).to("cuda:0"), -1.0, 1.0)
+        O.env_step(cfg, s, a_o)
+        env.step(a_h)
+        obs_o = torch.from_numpy(s.obs.copy())
+        obs_h = env.obs_buf
+        ep_ret += s.reward; ep_len += 1
+        fin = s.reset != 0
+        done_ret += float(ep_ret[fin].sum()); done_len += float(ep_len[fin].sum()); done_cnt += int(fin.sum())
+        ep_ret[fin] = 0; ep_len[fin] = 0
+        var = np.float32(max(np.float32(0.01), np.float32(var - np.float32(0.00001))))
+    mr, ml, cnt = env.episode_stats()
+    env.exit()
+    o_ret = done_ret / max(done_cnt, 1)
+    o_len = done_len / max(done_cnt, 1)
+    return {"hip": round(mr, 4), "oracle": round(o_ret, 4), "rel_diff": round(abs(mr - o_ret) / (abs(o_ret) + 1e-9), 5),
+            "episodes": {"hip": cnt, "oracle": done_cnt}, "mean_length": {"hip": round(ml, 2), "oracle": round(o_len, 2)},
+            "env_steps": steps, "num_envs": num_envs, "seconds": round(time.perf_counter() - t0, 1),
+            "note": "statistical: both sides start from the reference reset state with the same initial weights, the same recorded "
+                    "eps and the variance schedule of ppo.py:152/:236-237, no update; each runs closed-loop on its own observations "
+                    "(fp32 trajectories part chaotically), so means over finished episodes are compared, not trajectories.  The "
+                    "reference itself logs only the mean per-step reward (ppo.py:233)"}
 
 
 def dry_run(a):
@@ -612,11 +790,14 @@ def main():
     steps_done = agent.optim_step
     # rollout-only rate (no update) for the breakdown
     agent.args.testing = True
-    fence()
-    r0 = time.perf_counter()
     iteration()
     fence()
-    rollout_s = time.perf_counter() - r0
+    ROLL_REPS = 5               # back to back: one fence's sync latency (~0.1 ms) would be 5 % of a single 1.8 ms rollout
+    r0 = time.perf_counter()
+    for _ in range(ROLL_REPS):
+        iteration()
+    fence()
+    rollout_s = (time.perf_counter() - r0) / ROLL_REPS
     # labelled A/B: the same rollout with one launch per env step (`persistent_rollout=False`; the default is ONE launch per
     # rollout, ppo_rollout_all, with per-step reset / progress rows)
     persist_s = None
@@ -626,9 +807,10 @@ def main():
         iteration()
         fence()
         p0 = time.perf_counter()
-        iteration()
+        for _ in range(ROLL_REPS):
+            iteration()
         fence()
-        persist_s = time.perf_counter() - p0
+        persist_s = (time.perf_counter() - p0) / ROLL_REPS
     finally:
         agent.persistent_rollout = was_persistent
     agent.args.testing = False
@@ -722,6 +904,10 @@ def main():
                 line["dqn"] = {"error": repr(e)[:200]}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.num_envs)
+            try:        # the second half of BASELINE's metric, beside the oracle (same leg: the only place bench.py touches oracle/)
+                line["episode_return_vs_oracle"] = episode_return_vs_oracle(a.num_envs)
+            except Exception as e:      # noqa: BLE001
+                line["episode_return_vs_oracle"] = {"error": repr(e)[:200]}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

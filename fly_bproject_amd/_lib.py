@@ -47,7 +47,7 @@ SYMBOLS = {
     "mlp_grad_w": [_P] * 8 + [_L, _P, _P, _P, _P, _P, _P, _I, _P],
     "mlp_fused_workspace_floats": [],
     "mlp_fused_grad": [_P] * 3 + [_P, _L] + [_P] * 5 + [_F, _F] + [_P] * 6 + [C.POINTER(_P), _P],
-    "mlp_adam_step": [_P] * 10 + [_F, _F, _F, _F, _F, _F, _P, _I, _P, _P, _P, _P, _P, _P],
+    "mlp_adam_step": [_P] * 10 + [_F, _F, _F, _F, _F, _F, _P, _I, _P, _P, _P, _P, _P, _P, _P],
     "dqn_eps_greedy": [_P, _P, _P, _F, _I, _P, _L, _P],
     "dqn_huber_td": [_P, _P, _P, _P, _P, _F, _I, _L, _P, _P, _P],
     "dqn_forward": [_P, _P, _P, _L, _P, _P],

@@ -104,8 +104,9 @@ extern "C" hipError_t flyhip_launch_p2p_allreduce(float* G, int64_t n, void* con
 {
     // how long a rank waits for a late peer (checkpoint save, first-use lazy loading, GC): 2^24 polls with s_sleep
     // are several seconds; FLY_P2P_POLL_LOG2 overrides it
-    static int budget = 0;
-    if (!budget) {
+    // (read per launch: a getenv costs nothing next to a launch, and the tests lower it after the start-up self-test)
+    int budget;
+    {
         const char* e = getenv("FLY_P2P_POLL_LOG2");
         int lg = e ? atoi(e) : 24;
         if (lg < 4) lg = 4;

@@ -63,7 +63,7 @@ extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PF, float* PT, con
                                              float* v, int* step, float lr, float beta1, float beta2, float eps,
                                              float max_norm, float grad_scale, float* norm_ws, int norm_ready,
                                              uint16_t* PB, uint16_t* PTB, const int* idx_fb, const int* idx_tb,
-                                             int* step_out, void* stream);
+                                             int* step_out, const int* grad_invalid, void* stream);
 
 extern "C" hipError_t flyhip_launch_bookkeeping(const float* reward, int64_t n, float* score_acc, float score_scale,
                                                 float* action_var, int nvar, float var_decay, float var_min,
@@ -92,7 +92,8 @@ extern "C" hipError_t flyhip_launch_rollout_all(const FlyConfig* dcfg, const Fly
                                                 float* obs_ring, int64_t n, const float* eps_all, const float* var,
                                                 float var_decay, float var_min, float* act_all, float* logp_all, float* v_ring,
                                                 float* reward_all, int T, const int* rows_applied, const uint16_t* PB,
-                                                int64_t* reset_rows, int64_t* progress_rows, void* stream);
+                                                int64_t* reset_rows, int64_t* progress_rows, void* stream,
+                                                unsigned long long* stamps);
 extern "C" hipError_t flyhip_launch_rollout_bookkeeping(const float* reward, int64_t rows, int64_t n, float* terms,
                                                         float* score_acc, float score_scale, float* action_var, int nvar,
                                                         float var_decay, float var_min, int* rows_applied, void* stream);
@@ -164,7 +165,7 @@ int launch(FlyHandle h, int phases, const float* actions, const FlyBuffers* b, v
 extern "C" {
 
 const char* fly_last_error(void) { return g_err; }
-int fly_abi_version(void) { return 7; }
+int fly_abi_version(void) { return 8; }
 
 int fly_create(const FlyConfig* cfg, FlyHandle* out)
 {
@@ -221,10 +222,11 @@ int ppo_rollout_step(FlyHandle h, const FlyBuffers* b, const float* params, cons
     return FLY_OK;
 }
 
-int ppo_rollout_all(FlyHandle h, const FlyBuffers* b, const float* params, const float* params_frag, float* obs_ring,
-                    const float* eps_all, const float* var, float var_decay, float var_min, float* act_all,
-                    float* logp_all, float* v_ring, float* reward_all, int32_t T, const int32_t* rows_applied,
-                    const uint16_t* params_b3, int64_t* reset_rows, int64_t* progress_rows, void* stream)
+static int rollout_all_impl(FlyHandle h, const FlyBuffers* b, const float* params, const float* params_frag, float* obs_ring,
+                            const float* eps_all, const float* var, float var_decay, float var_min, float* act_all,
+                            float* logp_all, float* v_ring, float* reward_all, int32_t T, const int32_t* rows_applied,
+                            const uint16_t* params_b3, int64_t* reset_rows, int64_t* progress_rows, void* stream,
+                            unsigned long long* stamps)
 {
     if ((reset_rows != nullptr) != (progress_rows != nullptr)) return fail(FLY_E_ARG, "ppo_rollout_all: reset_rows and progress_rows go together");
     if (!h) return fail(FLY_E_ARG, "handle is null");
@@ -238,9 +240,31 @@ int ppo_rollout_all(FlyHandle h, const FlyBuffers* b, const float* params, const
     if (rc) return rc;
     hipError_t e = flyhip_launch_rollout_all(h->dev, &bb, params, params_frag, obs_ring, h->host.num_envs, eps_all, var,
                                              var_decay, var_min, act_all, logp_all, v_ring, reward_all, T, rows_applied,
-                                             params_b3, reset_rows, progress_rows, stream);
+                                             params_b3, reset_rows, progress_rows, stream, stamps);
     if (e != hipSuccess) return hip_fail(e, "ppo_rollout_all launch");
     return FLY_OK;
+}
+
+int ppo_rollout_all(FlyHandle h, const FlyBuffers* b, const float* params, const float* params_frag, float* obs_ring,
+                    const float* eps_all, const float* var, float var_decay, float var_min, float* act_all,
+                    float* logp_all, float* v_ring, float* reward_all, int32_t T, const int32_t* rows_applied,
+                    const uint16_t* params_b3, int64_t* reset_rows, int64_t* progress_rows, void* stream)
+{
+    return rollout_all_impl(h, b, params, params_frag, obs_ring, eps_all, var, var_decay, var_min, act_all, logp_all, v_ring,
+                            reward_all, T, rows_applied, params_b3, reset_rows, progress_rows, stream, nullptr);
+}
+
+// diagnostic: the same launch through the stamped instantiation of rollout_all_fs_kernel (bench.py's policy / env split of a
+// rollout step, tools/stamp_rollout.py); stamps u64 [workgroups][T + 1][2].  Not part of the ABI header.
+extern "C" int flyhip_debug_rollout_all_stamped(FlyHandle h, const FlyBuffers* b, const float* params, const float* params_frag,
+                                                float* obs_ring, const float* eps_all, const float* var, float var_decay,
+                                                float var_min, float* act_all, float* logp_all, float* v_ring, float* reward_all,
+                                                int32_t T, const uint16_t* params_b3, int64_t* reset_rows, int64_t* progress_rows,
+                                                unsigned long long* stamps, void* stream)
+{
+    if (!stamps) return fail(FLY_E_ARG, "stamps is null");
+    return rollout_all_impl(h, b, params, params_frag, obs_ring, eps_all, var, var_decay, var_min, act_all, logp_all, v_ring,
+                            reward_all, T, nullptr, params_b3, reset_rows, progress_rows, stream, stamps);
 }
 
 int fly_scale_actions(FlyHandle h, const float* actions, float* targets, void* stream)
@@ -434,7 +458,8 @@ int mlp_adam_step(float* params, float* params_frag, float* params_t_frag, const
                   const int32_t* idx_t_frag, const float* grad, const float* mask, float* exp_avg,
                   float* exp_avg_sq, int32_t* step, float lr, float beta1, float beta2, float eps,
                   float max_norm, float grad_scale, float* norm_ws, int32_t norm_ready, uint16_t* params_b3,
-                  uint16_t* params_t_b3, const int32_t* idx_b3, const int32_t* idx_t_b3, int32_t* step_out, void* stream)
+                  uint16_t* params_t_b3, const int32_t* idx_b3, const int32_t* idx_t_b3, int32_t* step_out,
+                  const int32_t* grad_invalid, void* stream)
 {
     if (params_b3 && (!params_t_b3 || !idx_b3 || !idx_t_b3))
         return fail(FLY_E_ARG, "mlp_adam_step: params_b3 needs params_t_b3, idx_b3 and idx_t_b3");
@@ -443,7 +468,7 @@ int mlp_adam_step(float* params, float* params_frag, float* params_t_frag, const
         return fail(FLY_E_ARG, "mlp_adam_step: null pointer");
     hipError_t e = flyhip_launch_mlp_adam(params, params_frag, params_t_frag, idx_frag, idx_t_frag, grad, mask, exp_avg, exp_avg_sq, step, lr, beta1, beta2,
                                           eps, max_norm, grad_scale, norm_ws, norm_ready, params_b3, params_t_b3, idx_b3, idx_t_b3,
-                                          step_out, stream);
+                                          step_out, grad_invalid, stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_adam_step launch");
     return FLY_OK;
 }

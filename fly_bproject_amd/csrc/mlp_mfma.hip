@@ -142,33 +142,54 @@ __global__ __launch_bounds__(THREADS, WPS) void rollout_all_kernel(
 // The same loop with the policy in the fused step's style (policy_tile_fs, mlp_fused_step.inc): swizzled plane images, the chain
 // GEMMs' asm MFMA streams, 135 KB of LDS -- one workgroup per CU, whole tiles only (the launcher checks both).  The env step
 // stages its observation block in H2's region of that image, which is where the next step's policy converts it from.
+// STAMP (diagnostic instantiation, bench.py / tools/stamp_rollout.py): thread 0 of every workgroup stores s_memtime at the top of
+// each step and between its policy and env halves into stamps u64 [workgroup][T + 1][2] (+ the 100 MHz real-time counter once).
+// MULTI: more tiles than workgroups (> 8192 envs on 256 CUs): the outer loop really loops; the single-tile instantiation keeps
+// the register allocation of a kernel without it.
+template <bool STAMP, bool MULTI>
 __global__ __launch_bounds__(THREADS, 1) void rollout_all_fs_kernel(
     const FlyConfig* __restrict__ c, FlyBuffers b, const float* __restrict__ P, const u16* __restrict__ PB,
     float* __restrict__ obs_ring, long n, const float* __restrict__ eps_all, const float* __restrict__ var, float var_decay,
     float var_min, float* __restrict__ act_all, float* __restrict__ logp_all, float* __restrict__ v_ring,
-    float* __restrict__ reward_all, int T, int64_t* __restrict__ reset_rows, int64_t* __restrict__ progress_rows)
+    float* __restrict__ reward_all, int T, int64_t* __restrict__ reset_rows, int64_t* __restrict__ progress_rows,
+    unsigned long long* __restrict__ stamps)
 {
     extern __shared__ __attribute__((aligned(16))) u16 fr_lds[];
     const FrLds L(fr_lds);
     constexpr int PH_ALL = PH_SCALE | PH_RESET | PH_INTEGRATE | PH_OBS | PH_PROGRESS | PH_REWARD;
-    if (threadIdx.x < 32) L.varcur[threadIdx.x] = threadIdx.x < MLP_NACT ? var[threadIdx.x] : 1.0f;   // the variance of row 0 (see rollout_all_kernel)
     policy_tile_fs_setup(L, P);
-    FlyRegs st;
-    fly_load<PH_ALL>(st, c, b, blockIdx.x);
-    __syncthreads();
-    for (int t = 0; t < T; ++t) {
-        float* act = act_all + (long)t * n * MLP_NACT;
-        b.obs = obs_ring + (long)(t + 1) * n * FLY_NUM_OBS;
-        b.reward = reward_all + (long)t * n;
-        if (reset_rows) { b.reset = reset_rows + (long)t * n; b.progress = progress_rows + (long)t * n; }   // fly.py:175-177, per step
-        policy_tile_fs(L, blockIdx.x, PB, t == 0 ? obs_ring : nullptr, n, v_ring + (long)t * n, eps_all + (long)t * n * MLP_NACT, act,
-                       logp_all + (long)t * n);
-        FlyRegs nx;
-        fly_body<PH_ALL>(c, act, b, L.obs, blockIdx.x, st, &nx, L.acts);
-        st = nx;
-        if (threadIdx.x < MLP_NACT && var_decay > 0.0f) L.varcur[threadIdx.x] = fmaxf(var_min, L.varcur[threadIdx.x] - var_decay);
+    int64_t* const reset0 = b.reset;                          // the CURRENT flags: read once per tile, before the tile's step 0
+    int64_t* const progress0 = b.progress;
+    const long ntiles = n / BM;                               // whole tiles only (the launcher checks)
+    // persistent over tiles: workgroup g runs the T steps of tiles g, g + grid, ... one after the other (one tile per workgroup at
+    // <= 8192 envs on 256 CUs; two at 16384).  Tiles are independent, so the order is free and every row equals the per-step launches'.
+    long tile = blockIdx.x;
+    do {
+        unsigned long long* st_tile = STAMP ? stamps + tile * (T + 1) * 2 : nullptr;
+        if (threadIdx.x < 32) L.varcur[threadIdx.x] = threadIdx.x < MLP_NACT ? var[threadIdx.x] : 1.0f;   // the variance of row 0 (see rollout_all_kernel)
+        b.reset = reset0; b.progress = progress0;
+        FlyRegs st;
+        fly_load<PH_ALL>(st, c, b, (int)tile);
         __syncthreads();
-    }
+        for (int t = 0; t < T; ++t) {
+            stamp<STAMP>(st_tile, 2 * t);
+            float* act = act_all + (long)t * n * MLP_NACT;
+            b.obs = obs_ring + (long)(t + 1) * n * FLY_NUM_OBS;
+            b.reward = reward_all + (long)t * n;
+            if (reset_rows) { b.reset = reset_rows + (long)t * n; b.progress = progress_rows + (long)t * n; }   // fly.py:175-177, per step
+            policy_tile_fs(L, tile, PB, t == 0 ? obs_ring : nullptr, n, v_ring + (long)t * n, eps_all + (long)t * n * MLP_NACT, act,
+                           logp_all + (long)t * n);
+            stamp<STAMP>(st_tile, 2 * t + 1);
+            FlyRegs nx;
+            fly_body<PH_ALL>(c, act, b, L.obs, (int)tile, st, &nx, L.acts);
+            st = nx;
+            if (threadIdx.x < MLP_NACT && var_decay > 0.0f) L.varcur[threadIdx.x] = fmaxf(var_min, L.varcur[threadIdx.x] - var_decay);
+            __syncthreads();
+        }
+        stamp<STAMP>(st_tile, 2 * T);
+        if (STAMP && threadIdx.x == 0) st_tile[2 * T + 1] = realtime_cu();
+        tile += gridDim.x;
+    } while (MULTI && tile < ntiles);
 }
 
 }  // namespace
@@ -177,25 +198,39 @@ extern "C" hipError_t flyhip_launch_rollout_all(const FlyConfig* dcfg, const Fly
                                                 float* obs_ring, int64_t n, const float* eps_all, const float* var,
                                                 float var_decay, float var_min, float* act_all, float* logp_all, float* v_ring,
                                                 float* reward_all, int T, const int* rows_applied, const uint16_t* PB,
-                                                int64_t* reset_rows, int64_t* progress_rows, void* stream)
+                                                int64_t* reset_rows, int64_t* progress_rows, void* stream,
+                                                unsigned long long* stamps)
 {
     const dim3 grid((unsigned)((n + BM - 1) / BM));
     int cus = 256;
     { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; }
     const bool one_per_cu = (int)grid.x <= cus;
-    static const bool fs_off = getenv("FLY_ROLLOUT_FS") != nullptr && getenv("FLY_ROLLOUT_FS")[0] == '0';
-    if (PB && one_per_cu && n % BM == 0 && !fs_off) {       // the policy body in the fused step's style (A/B: FLY_ROLLOUT_FS=0)
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_all_fs_kernel),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, FR_LDS_BYTES);
+    const dim3 grid_fs((unsigned)((int)grid.x <= cus ? (int)grid.x : cus));   // the fused-style kernel walks its tiles itself
+    const char* fs_env = getenv("FLY_ROLLOUT_FS");               // read per launch: the tests flip it inside one process
+    const bool fs_off = fs_env != nullptr && fs_env[0] == '0';
+    if (PB && n % BM == 0 && !fs_off) {       // the policy body in the fused step's style (A/B: FLY_ROLLOUT_FS=0); persistent over tiles
+        static bool attr_set[4] = {false, false, false, false};
+        const bool multi = (int)grid.x > cus;
+        const int si = (stamps ? 1 : 0) + (multi ? 2 : 0);
+        const void* fn = si == 0 ? reinterpret_cast<const void*>(rollout_all_fs_kernel<false, false>)
+                       : si == 1 ? reinterpret_cast<const void*>(rollout_all_fs_kernel<true, false>)
+                       : si == 2 ? reinterpret_cast<const void*>(rollout_all_fs_kernel<false, true>)
+                                 : reinterpret_cast<const void*>(rollout_all_fs_kernel<true, true>);
+        if (!attr_set[si]) {
+            hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, FR_LDS_BYTES);
             if (ea != hipSuccess) return ea;
-            attr_set = true;
+            attr_set[si] = true;
         }
-        hipLaunchKernelGGL(rollout_all_fs_kernel, grid, dim3(THREADS), FR_LDS_BYTES, (hipStream_t)stream, dcfg, *b, P, PB, obs_ring, (long)n,
-                           eps_all, var, var_decay, var_min, act_all, logp_all, v_ring, reward_all, T, reset_rows, progress_rows);
+#define RAFS_LAUNCH(S_, M_)                                                                                                           \
+        hipLaunchKernelGGL((rollout_all_fs_kernel<S_, M_>), grid_fs, dim3(THREADS), FR_LDS_BYTES, (hipStream_t)stream, dcfg, *b, P, PB,   \
+                           obs_ring, (long)n, eps_all, var, var_decay, var_min, act_all, logp_all, v_ring, reward_all, T, reset_rows,  \
+                           progress_rows, stamps)
+        if (si == 0) RAFS_LAUNCH(false, false); else if (si == 1) RAFS_LAUNCH(true, false);
+        else if (si == 2) RAFS_LAUNCH(false, true); else RAFS_LAUNCH(true, true);
+#undef RAFS_LAUNCH
         return hipGetLastError();
     }
+    if (stamps) return hipErrorInvalidValue;        // only the fused-style kernel has a stamped instantiation
 #define RA_LAUNCH(B3_, WPS_, PF_)                                                                                                  \
     hipLaunchKernelGGL((rollout_all_kernel<B3_, WPS_>), grid, dim3(THREADS), 0, (hipStream_t)stream, dcfg, *b, P, (const void*)PF_, \
                        obs_ring, (long)n, eps_all, var, var_decay, var_min, act_all, logp_all, v_ring, reward_all, T, rows_applied, reset_rows, \
@@ -508,7 +543,7 @@ extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PF, float* PT, con
                                              float* v, int* step, float lr, float beta1, float beta2, float eps,
                                              float max_norm, float grad_scale, float* norm_ws, int norm_ready,
                                              uint16_t* PB, uint16_t* PTB, const int* idx_fb, const int* idx_tb,
-                                             int* step_out, void* stream)
+                                             int* step_out, const int* grad_invalid, void* stream)
 {
     int nparts = ADAM_BLOCKS;
     float part_scale = 1.0f;
@@ -519,12 +554,12 @@ extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PF, float* PT, con
         part_scale = grad_scale * grad_scale;
     } else {
         hipLaunchKernelGGL(mlp_adam_norm_kernel, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, G, mask,
-                           grad_scale, norm_ws, step);
+                           grad_scale, norm_ws, step, grad_invalid);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(mlp_adam_apply_kernel, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, P, PF, PT,
                        idx_f, idx_t, G, mask, m, v, step, lr, beta1, beta2, eps, max_norm, grad_scale, norm_ws, nparts,
-                       part_scale, PB, PTB, idx_fb, idx_tb, step_out);
+                       part_scale, PB, PTB, idx_fb, idx_tb, step_out, grad_invalid);
     return hipGetLastError();
 }

@@ -397,11 +397,12 @@ class PackedPolicy:
         """Device int32 [1]: optimizer steps applied so far."""
         return self._step2[self._step_idx:self._step_idx + 1]
 
-    def adam_step(self, grad_scale=1.0, norm_ready=False, self_norm=False):
+    def adam_step(self, grad_scale=1.0, norm_ready=False, self_norm=False, grad_invalid=None):
         """clip_grad_norm_ + Adam on the packed parameters.  norm_ready: mlp_grad_w has already left the norm
         partials and advanced the step (single rank).  self_norm: ONE launch that also sums the gradient
         (data-parallel ranks: G comes out of the all-reduce); the step counter then ping-pongs between two
-        device words so that no workgroup reads a value another one has already advanced."""
+        device words so that no workgroup reads a value another one has already advanced.  grad_invalid: optional int32 device
+        word (the err word of the peer-to-peer exchange); nonzero = the launch refuses the step (fail closed)."""
         p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
         self.version += 1
         self.steps_issued += 1
@@ -415,5 +416,6 @@ class PackedPolicy:
                                            p(self.exp_avg_sq), p(step_in), C.c_float(self.lr),
                                            C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
                                            C.c_float(self.max_norm), C.c_float(grad_scale), p(self._norm_ws),
-                                           C.c_int(1 if norm_ready else 0), *self._plane_args(), step_out, _lib.stream_ptr()),
+                                           C.c_int(1 if norm_ready else 0), *self._plane_args(), step_out,
+                                           p(grad_invalid) if grad_invalid is not None else None, _lib.stream_ptr()),
                    "mlp_adam_step")

@@ -137,6 +137,10 @@ class PPO:
             want_async = os.environ.get("FLY_ASYNC_LOG", "1") != "0"
         self._async_log = bool(want_async) and dev.type == "cuda"
         self._log_q = collections.deque()
+        # opt-in (`--log_throughput`): the score line also carries env-steps/s (all ranks) over the steps since the previous score
+        # line, by the host's clock.  Off by default: stdout then is the reference's lines (ppo.py:257-260), character for character.
+        self.log_throughput = bool(getattr(args, "log_throughput", False))
+        self._rate_mark = None                                      # (perf_counter, run_step) of the previous score line
         self._pending_step = None                                   # deferred check of the device step counter (_update_hip)
         self.env.bind_obs(self._obs_ring[0])                        # first policy input: zeros (Q8)
 
@@ -343,21 +347,37 @@ class PPO:
                         self._p2p.allreduce_(pol.G)                 # one launch, one xGMI hop, sum in rank order
                     else:
                         dist.all_reduce(pol.G, op=dist.ReduceOp.SUM)    # 297 KB, latency-bound on xGMI
+                # either way ONE optimizer launch per step; it reads the exchange's err word itself and refuses a gradient
+                # that ANY workgroup of the exchange left un-reduced (fail closed, on the device)
                 pol.adam_step(grad_scale=1.0 / self.world_size if sync_grads else 1.0, norm_ready=not sync_grads,
-                              self_norm=sync_grads)       # either way ONE optimizer launch per step
+                              self_norm=sync_grads, grad_invalid=self._p2p.err if (sync_grads and self._p2p is not None) else None)
 
         self._check_step_counter()       # the previous update's counter, copied while this rollout ran
         run(slices)
-        if not pol.update_can_be_refused() and self._p2p is None and self._async_log:
+        if self._p2p is not None and not self._p2p.check():
+            # FIRST, before anything looks at the step counter: a bounded wait of the peer-to-peer exchange expired on this
+            # rank.  Its optimizer launches have refused the un-reduced gradients (fail closed) and the counter is behind, but
+            # redoing steps is no remedy here -- no peer is at those epochs.  Fatal by design (dist.py: "the caller must stop").
+            raise _lib.FlyHipError("dp_allreduce_p2p: a rank never published its gradient (bounded wait expired; "
+                                   "FLY_P2P_POLL_LOG2 raises the budget, --dp_allreduce rccl avoids the kernel)")
+        if not pol.update_can_be_refused():
             # No launch of this update path can leave an invalid gradient (the fused optimizer step hands nothing from workgroup to
-            # workgroup), so the device counter only CONFIRMS the count: it is copied asynchronously and compared when the next
-            # update begins (or at exit) -- the host goes straight on to the next rollout instead of draining the queue here
-            # (measured: ~120 us of launch-bound idle per iteration behind a blocking read).
-            host = torch.empty(1, dtype=pol.step.dtype, pin_memory=True)
-            host.copy_(pol.step, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            self._pending_step = (ev, host, pol.steps_issued)
+            # workgroup), so the device counter only CONFIRMS the count.
+            if self._p2p is None and self._async_log:
+                # copied asynchronously and compared when the next update begins (or at exit) -- the host goes straight on to the
+                # next rollout instead of draining the queue here (measured: ~120 us of launch-bound idle per iteration behind a
+                # blocking read)
+                host = torch.empty(1, dtype=pol.step.dtype, pin_memory=True)
+                host.copy_(pol.step, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._pending_step = (ev, host, pol.steps_issued)
+            else:
+                got = int(pol.step.item())
+                if got != pol.steps_issued:
+                    raise _lib.FlyHipError("update: the device step counter says %d optimizer steps, %d were issued"
+                                           % (got, pol.steps_issued))
+                self._drain_log(block=True)
             self.optim_step += len(slices)
             self._finish_update(sync_grads)
             return
@@ -365,7 +385,8 @@ class PPO:
         # leaves an invalid gradient; the optimizer kernels refuse such a step ON THE DEVICE (on every
         # rank: the flag rides inside the all-reduced gradient), and every later step of this update too.
         # So the device step counter says how many minibatches really happened: redo the rest through the
-        # two-launch path -- bit for bit what an undisturbed update leaves.
+        # two-launch path -- bit for bit what an undisturbed update leaves.  (Only this path -- the tile
+        # hand-off of mlp_forward_backward -- is ever redone.)
         for attempt in range(3):
             short = pol.steps_issued - int(pol.step.item())
             if pol.fuse_fwd_bwd or short:
@@ -379,12 +400,10 @@ class PPO:
             print("mlp_forward_backward: %d of %d optimizer steps were refused on the device (a backward workgroup "
                   "could not get its tile); redoing them with two launches" % (short, len(slices)))
             run(slices[len(slices) - short:])
+            if self._p2p is not None and not self._p2p.check():
+                raise _lib.FlyHipError("dp_allreduce_p2p: a rank never published its gradient while refused steps were redone")
         self.optim_step += len(slices)
         self._drain_log(block=True)                     # the queue is drained anyway: pending log lines cost nothing here
-        if self._p2p is not None and not self._p2p.check():
-            # fatal by design: this rank's optimizer refused the un-reduced gradients (fail closed), its peers cannot know
-            raise _lib.FlyHipError("dp_allreduce_p2p: a rank never published its gradient (bounded wait expired; "
-                                   "FLY_P2P_POLL_LOG2 raises the budget, --dp_allreduce rccl avoids the kernel)")
         self._finish_update(sync_grads)
 
     def _finish_update(self, sync_grads):
@@ -555,16 +574,31 @@ class PPO:
         self._log_q.append(text)
         self._drain_log()
 
+    def _throughput_suffix(self):
+        """' | Env-steps/s ...' for the score line when `log_throughput` is on: env steps of all ranks since the previous score
+        line over the host's wall clock (inside a rollout that runs as ONE launch the host counts ahead of the device, so a
+        window is exact only from rollout boundary to rollout boundary; over several windows it is the loop's rate)."""
+        if not self.log_throughput:
+            return ""
+        import time
+        now, mark = time.perf_counter(), self._rate_mark
+        self._rate_mark = (now, self.run_step)
+        if mark is None or now <= mark[0]:
+            return " | Env-steps/s n/a"
+        steps = (self.run_step - mark[1]) * int(self.args.num_envs) * self.world_size
+        return " | Env-steps/s {:.4g}".format(steps / (now - mark[0]))
+
     def _emit_score(self):
         """ppo.py:257-260: the score line of this step.  Values are read from the device asynchronously (pinned memory + event);
         the accumulator is cleared on the stream, behind the copy."""
         rank0 = int(getattr(self.args, "rank", 0)) == 0
+        suffix = self._throughput_suffix()
         if not self._async_log:
             self._drain_log(block=True)
             score = float(self._score_acc.item())
             self._score_acc.zero_()
             if rank0:
-                print(self.SCORE_LINE.format(self.run_step, self.optim_step, score, self._action_var[0].item()))
+                print(self.SCORE_LINE.format(self.run_step, self.optim_step, score, self._action_var[0].item()) + suffix)
             return
         dev_vals = torch.stack((self._score_acc.reshape(()), self._action_var[0]))
         host = torch.empty(2, dtype=torch.float32, pin_memory=True)
@@ -572,7 +606,7 @@ class PPO:
         ev = torch.cuda.Event()
         ev.record()
         self._score_acc.zero_()
-        self._log_q.append((ev, host, dev_vals, self.run_step, self.optim_step, rank0))
+        self._log_q.append((ev, host, dev_vals, self.run_step, self.optim_step, rank0, suffix))
         self._drain_log()
 
     def _drain_log(self, block=False):
@@ -583,13 +617,13 @@ class PPO:
             if isinstance(head, str):
                 print(head)
             else:
-                ev, host, _keep, run_step, optim_step, rank0 = head
+                ev, host, _keep, run_step, optim_step, rank0, suffix = head
                 if block:
                     ev.synchronize()
                 elif not ev.query():
                     return
                 if rank0:
-                    print(self.SCORE_LINE.format(run_step, optim_step, float(host[0]), float(host[1])))
+                    print(self.SCORE_LINE.format(run_step, optim_step, float(host[0]), float(host[1])) + suffix)
             q.popleft()
 
     def flush_log(self):

@@ -257,7 +257,9 @@ int ppo_rollout_step(FlyHandle h, const FlyBuffers* b, const float* params, cons
  * eps_all / act_all f32 [T][N][18], logp_all / v_ring f32 [T][N] (v_ring may be [T+1][N]), reward_all f32 [T][N] --
  * with the env state carried in registers from step to step (`b` gives the state tensors; its obs / reward members
  * are ignored).  Envs of a 32-env tile depend on no other tile and the policy is constant inside a rollout, so each
- * workgroup runs its own tile's T steps.  Row t decays the variance (t - *rows_applied) times (rows_applied optional).
+ * workgroup runs its own tile's T steps.  `var` must ALREADY be the variance of row 0: the launch is the first device work of
+ * its rollout and decays it once per step from there; `rows_applied` is ignored (kept for the ABI's shape: the per-step entry
+ * ppo_rollout_step is the one that subtracts it) -- a caller with decays still pending applies them before this call.
  * Bit for bit what T calls of ppo_rollout_step leave.  The launch runs for T x (one step's time): keep T <= a few
  * thousand.  reset_rows / progress_rows (both or neither, int64 [T][N]): step t writes its reset / progress flags to row t
  * instead of b->reset / b->progress (which are then only READ, once, at the start), so that a host that walks the rollout
@@ -299,8 +301,11 @@ int ppo_rollout_all(FlyHandle h, const FlyBuffers* b, const float* params, const
  *                     comes out of an all-reduce): ONE launch -- every workgroup sums the masked
  *                     gradient itself (norm_ready is ignored) and the counter ping-pongs: *step is
  *                     only read, *step_out = *step + 1 is written; pass the two words alternately.
- *                     FAIL CLOSED: with grad[76] != 0 (see mlp_grad_w) the
- *                     call changes nothing -- parameters, moments and *step keep their values.
+ *                     FAIL CLOSED: with grad[76] != 0 (see mlp_grad_w), or with *grad_invalid != 0
+ *                     (optional device word, NULL = none: the err word of dp_allreduce_p2p, which ANY of
+ *                     its workgroups sets when it gave up on a peer -- so a gradient that is only partly
+ *                     reduced is refused as well), the call changes nothing -- parameters, moments and
+ *                     *step keep their values.
  */
 int64_t mlp_grad_workspace_floats(void);
 int mlp_backward_dx(const float* params_t_frag, const float* out_saved, const float* h1_saved,
@@ -366,7 +371,7 @@ int mlp_adam_step(float* params, float* params_frag, float* params_t_frag, const
                   float* exp_avg_sq, int32_t* step, float lr, float beta1, float beta2, float eps,
                   float max_norm, float grad_scale, float* norm_ws, int32_t norm_ready,
                   uint16_t* params_b3, uint16_t* params_t_b3, const int32_t* idx_b3,
-                  const int32_t* idx_t_b3, int32_t* step_out, void* stream);
+                  const int32_t* idx_t_b3, int32_t* step_out, const int32_t* grad_invalid, void* stream);
 
 
 /*

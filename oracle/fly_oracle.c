@@ -269,6 +269,45 @@ void orc_pack_reward(const OrcConfig* c, const float* obs, const float* targets,
     }
 }
 
+/* ---- f4: the reference viewer's P-key dump of the reward terms, fly.py:504-546 ---------------
+ * terms [n][9] = heading_reward, alive_reward, up_reward, orient_reward, actions_cost, electricity_cost,
+ * dof_at_limit_cost (already times joints_at_limit_cost_scale, :531), progress_reward, leg_reward.
+ * NOT the reward's own terms: the dump's up_reward has no "- up_weight below 2.1" branch (:512-513 vs :719-721)
+ * and its orientation threshold is 0.92 (:518), the reward's is 0.98 (:728). */
+void orc_reward_terms(const OrcConfig* c, const float* obs, const float* targets, const float* root,
+                      const float* contact, const float* pot, const float* prev_pot, float* terms, int64_t n)
+{
+    const float uw = c->up_weight, hw = c->heading_weight;
+    _Pragma("omp parallel for schedule(static)")
+    for (int64_t e = 0; e < n; ++e) {
+        const float* o = obs + e * ORC_NOBS;
+        const float* act = targets + e * ORC_NDOF;
+        const float* q = root + e * 13 + 3;
+        float* t = terms + e * 9;
+        t[0] = (o[11] > 0.8f) ? hw : hw * o[11] / 0.8f;                        /* :507-508 */
+        t[1] = 0.5f;                                                           /* :510 */
+        t[2] = (o[0] > 1.4f) ? (0.0f + uw) : 0.0f;                             /* :512-513 */
+        t[3] = (q[2] * q[2] + q[3] * q[3] > 0.92f) ? (0.0f + uw) : 0.0f;       /* :517-518 */
+        float ac = 0.0f, elec = 0.0f;
+        int64_t lim = 0;
+        for (int j = 0; j < ORC_NDOF; ++j) {
+            ac += act[j] * act[j];                                             /* :521 */
+            elec += fabsf(act[j] - o[48 + j]);                                 /* :524-525 */
+            if (o[48 + j] > c->dof_hi[j] * 0.9f) ++lim;                        /* :529 */
+            if (o[48 + j] < c->dof_lo[j] * 0.9f) ++lim;                        /* :530 */
+        }
+        t[4] = ac; t[5] = elec;
+        t[6] = (float)lim * c->joints_at_limit_cost_scale;                     /* :531 */
+        t[7] = pot[e] - prev_pot[e];                                           /* :532 */
+        int64_t touching = 0;                                                  /* :544 */
+        for (int k = 0; k < ORC_NLEG; ++k) {
+            const float* f = contact + (e * ORC_NCON + ORC_NABD + k) * 3;
+            if ((f[0] + f[1]) + f[2] > 0.0f) ++touching;
+        }
+        t[8] = (float)touching * 0.1f;
+    }
+}
+
 /* ---- a1: Fly.step orchestration, fly.py:624-681 (flyLowGrav.py swaps reset/simulate) ------- */
 void orc_env_step(const OrcConfig* c, const float* actions, float* root, float* dof_pos,
                   float* dof_vel, float* targets, float* contact, float* pot, float* prev_pot,

@@ -83,6 +83,10 @@ void orc_pack_obs(const OrcConfig* c, const float* root, const float* dof_pos, c
 void orc_pack_reward(const OrcConfig* c, const float* obs, const float* targets, const float* root,
                      const float* contact, const float* pot, const float* prev_pot,
                      int64_t* progress, float* reward, int64_t* reset, int64_t n);
+/* fly.py:504-546: the viewer's P-key dump, terms [n][9] (heading, alive, up, orient, actions_cost, electricity_cost,
+ * dof_at_limit_cost, progress_reward, leg_reward) */
+void orc_reward_terms(const OrcConfig* c, const float* obs, const float* targets, const float* root,
+                      const float* contact, const float* pot, const float* prev_pot, float* terms, int64_t n);
 /* fly.py:624-681 */
 void orc_env_step(const OrcConfig* c, const float* actions, float* root, float* dof_pos,
                   float* dof_vel, float* targets, float* contact, float* pot, float* prev_pot,

@@ -112,6 +112,18 @@ def pack_reward(cfg, s):
                           _p(s.reset, C.c_int64), C.c_int64(s.n))
 
 
+REWARD_TERMS = ("heading_reward", "alive_reward", "up_reward", "orient_reward", "actions_cost", "electricity_cost",
+                "dof_at_limit_cost", "progress_reward", "leg_reward")
+
+
+def reward_terms(cfg, s):
+    """fly.py:504-546 (the viewer's P-key dump) on the state's current buffers -> {name: f32 [n]}."""
+    t = np.zeros((s.n, 9), np.float32)
+    lib().orc_reward_terms(C.byref(cfg), _p(s.obs), _p(s.targets), _p(s.root), _p(s.contact), _p(s.pot), _p(s.prev_pot),
+                           _p(t), C.c_int64(s.n))
+    return {k: t[:, i].copy() for i, k in enumerate(REWARD_TERMS)}
+
+
 def env_step(cfg, s, actions):
     a = _f32(actions)
     assert a.shape == (s.n, NDOF)

@@ -134,3 +134,58 @@ def test_bench_gpus_2_on_one_gpu():
     assert line["grad_exchange_us_per_step"] > 0 and "rccl" in line["grad_exchange_variants_us"]
     assert line["grad_exchange_variants_us"].get("p2p", 0) > 0 and line["p2p_selftest"] == "passed"      # --p2p_variant
     assert line["refused_steps"] == 0
+
+
+def _late_peer_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    import contextlib
+    import io
+    import json
+    import torch.distributed as dist
+    from fly_bproject_amd import _lib
+    from fly_bproject_amd.dist import broadcast_policy
+    from fly_bproject_amd.ppo import PPO
+    from tests.hip_helpers import make_args
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    torch.manual_seed(0)
+    res = {"error": None}
+    with contextlib.redirect_stdout(io.StringIO()) as out:
+        agent = PPO(make_args(2048, rank=rank, world_size=world, seed=0, dp_allreduce="p2p"))
+        broadcast_policy(agent)
+        agent.prepare()                                   # windows + self-test with the default poll budget
+        assert agent._p2p is not None and agent.p2p_selftest == "passed"
+        os.environ["FLY_P2P_POLL_LOG2"] = "4"             # from here on a rank gives up on a peer after 16 polls
+        for _ in range(agent.rollout_size - 1):
+            agent.run()
+        torch.cuda.synchronize()
+        dist.barrier()
+        epochs_before = agent._p2p.epoch
+        if rank == 1:
+            torch.cuda._sleep(int(4e9))                   # the late peer: ~2 s before its update's first launch
+        try:
+            agent.run()                                   # the rollout's last step -> update -> 75 exchanges
+        except _lib.FlyHipError as e:
+            res["error"] = str(e)
+        res["epochs"] = agent._p2p.epoch - epochs_before
+        res["fuse_fwd_bwd"] = bool(agent.policy.fuse_fwd_bwd)
+        res["stdout"] = out.getvalue()[-2000:]
+    torch.cuda.synchronize()
+    with open(os.path.join(out_dir, "late%d.json" % rank), "w") as f:
+        json.dump(res, f)
+    dist.barrier()
+    agent._p2p.close()
+    dist.destroy_process_group()
+
+
+def test_p2p_late_peer_is_fatal_and_nothing_is_redone(tmp_path):
+    """A peer that arrives after the bounded wait (FLY_P2P_POLL_LOG2=4): the rank that gave up raises the P2P error -- not the
+    "device step counter is N steps behind" / "mlp_forward_backward ... refused" of the redo loop -- and issues NO further
+    dp_allreduce_p2p launch (exactly the 75 of the update: a redo would pair with the peers' NEXT epochs and hand them wrong
+    sums).  Its optimizer launches refused every un-reduced gradient on the device (fail closed)."""
+    import json
+    port = _free_port()
+    mp.spawn(_late_peer_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = json.load(open(tmp_path / "late0.json"))
+    assert r0["error"] is not None and "dp_allreduce_p2p" in r0["error"], r0
+    assert r0["epochs"] == 75, r0
+    assert "refused" not in r0["stdout"] and "steps behind" not in r0["error"]

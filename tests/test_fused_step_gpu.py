@@ -132,3 +132,53 @@ def test_fused_step_whole_update_matches_three_launch_update():
     moved = float((out[False] - init).norm())
     apart = float((out[True] - out[False]).norm())
     assert moved > 0 and apart <= 0.15 * moved, (apart, moved)     # 75 Adam steps amplify summation-order rounding (cf. test_ppo_hip_and_torch_updates_agree)
+
+
+@pytest.mark.parametrize("n,off", [(4099, 1), (40960, 3), (33, 2)])
+def test_fused_step_on_a_misaligned_x(n, off):
+    """x that is only 4-byte aligned (a minibatch slice of the rollout ring starts k * num_envs * 73 floats in: odd num_envs):
+    the LDS-DMA of 16-byte pieces needs 16-byte alignment, so such an x takes the guarded loads -- chain values and the
+    gradient equal those of the same rows at an aligned address bit for bit."""
+    net, ref, pol, (x, action, old_logp, adv, target, var) = _setup(n, 17, gemm="bf16x3")
+    pol.fused_step = True
+    _poison(pol)
+    pol.minibatch_grad(x, action, old_logp, adv, target, var, 0.2, dump=True)
+    torch.cuda.synchronize()
+    want, want_G, want_loss = _chain(pol, n), pol.G.clone(), pol.loss_part[: (n + 31) // 32].clone()
+    buf = torch.full((n * 73 + 8,), float("nan"), device=x.device)
+    xo = buf[off:off + n * 73].view(n, 73)
+    xo.copy_(x)
+    assert xo.data_ptr() % 16 != 0 and xo.is_contiguous()
+    _poison(pol)
+    pol.minibatch_grad(xo, action, old_logp, adv, target, var, 0.2, dump=True)
+    torch.cuda.synchronize()
+    got = _chain(pol, n)
+    for k in WIDTH:
+        assert torch.equal(got[k], want[k]), k
+    assert torch.equal(pol.G, want_G) and torch.equal(pol.loss_part[: (n + 31) // 32], want_loss)
+
+
+def test_ppo_with_an_odd_env_count_fused_vs_three_launch():
+    """num_envs = 4095 -> mini_chunk 10: every second minibatch slice of the ring is 4-byte aligned only.  One PPO iteration
+    through the fused step and through the three-launch path end close together (as test_fused_step_whole_update...)."""
+    import contextlib
+    import io
+    from fly_bproject_amd.ppo import PPO
+    from tests.hip_helpers import make_args
+    out, init = {}, None
+    for fused in (True, False):
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            agent = PPO(make_args(4095))
+            agent.policy.fused_step = fused
+            init = agent.policy.P.clone()
+            for _ in range(agent.rollout_size):
+                agent.run()
+        torch.cuda.synchronize()
+        assert agent.optim_step == 75 and int(agent.policy.step.item()) == 75
+        out[fused] = agent.policy.P.clone()
+        agent.exit()
+    assert torch.isfinite(out[True]).all()
+    moved = float((out[False] - init).norm())
+    apart = float((out[True] - out[False]).norm())
+    assert moved > 0 and apart <= 0.15 * moved, (apart, moved)

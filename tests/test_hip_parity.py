@@ -25,7 +25,7 @@ def lib():
 
 def test_library_is_the_hip_build(lib):
     l = lib.load()
-    assert l.fly_abi_version() == 7
+    assert l.fly_abi_version() == 8
     assert torch.cuda.is_available() and "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
 
 
@@ -111,6 +111,38 @@ def test_pack_reward_vs_reference_golden(golden, n, variant, ecs):
     env.exit()
 
 
+@pytest.mark.parametrize("n", [16, 257])
+def test_reward_terms_vs_oracle_on_golden_inputs(golden, n):
+    """`Fly.reward_terms()` (the reference viewer's P-key dump, fly.py:504-546) entry by entry against the oracle's restatement
+    on g2's inputs -- including the dump's 0.92 orientation threshold (fly.py:518; the reward itself uses 0.98, fly.py:728):
+    envs whose qz^2 + qw^2 lies between the two get the dump's orient_reward and no reward bonus."""
+    from fly_bproject_amd.fly import Fly
+    from tests.hip_helpers import make_args
+    g = golden("g2_reward")
+    p = "n%d_" % n
+    env = Fly(make_args(n))
+    s = O.EnvState(n)
+    s.obs[:] = g[p + "obs"]; s.targets[:] = g[p + "targets"]; s.root[:] = g[p + "root"]
+    s.contact[:] = g[p + "contact"]; s.pot[:] = g[p + "pot"]; s.prev_pot[:] = g[p + "prev_pot"]
+    s.progress[:] = g[p + "progress"]; s.reset[:] = g[p + "reset_in"]
+    push_state(env, s)
+    got = {k: v.float().cpu().numpy() for k, v in env.reward_terms().items()}
+    want = O.reward_terms(O.default_config(n), s)
+    assert set(got) == set(want) == set(O.REWARD_TERMS)
+    for k in ("alive_reward", "up_reward", "orient_reward", "leg_reward", "dof_at_limit_cost", "progress_reward"):
+        assert np.array_equal(got[k], want[k]), k                   # selections, counts and one subtraction: bit-exact
+    for k in ("heading_reward", "actions_cost", "electricity_cost"):
+        np.testing.assert_allclose(got[k], want[k], rtol=3e-6, atol=3e-6, err_msg=k)   # torch's reduction order over 18 terms
+    ori = s.root[:, 5] ** 2 + s.root[:, 6] ** 2
+    band = (ori > 0.92) & (ori <= 0.98)
+    assert band.sum() >= 1 and np.all(got["orient_reward"][band] == 0.75)
+    # and the reward of those envs carries no orientation bonus (0.98): the kernel's reward against the golden one
+    env.get_reward()
+    np.testing.assert_allclose(pull_state(env).reward, g[p + "big_reward"], rtol=3e-6, atol=3e-6)
+    assert float(want["electricity_cost"].max()) > 0                 # g2 feeds obs[48:66] != targets (Q4 is not in force here)
+    env.exit()
+
+
 def test_walking_reward_mode_vs_oracle():
     """reward_mode 1 = the walking formula the reference keeps commented out (fly.py:747-748);
     no reference run can pin it, the oracle restates the commented expression."""
@@ -172,12 +204,13 @@ def test_integrate_one_step_vs_oracle(variant):
     env.exit()
 
 
+@pytest.mark.parametrize("n", [256, 8192])
 @pytest.mark.parametrize("variant", ["bigGrav", "lowGrav"])
-def test_fused_step_vs_oracle_resynced(variant):
+def test_fused_step_vs_oracle_resynced(variant, n):
     """fly_step (one launch) against orc_env_step, restarted from the oracle's state every step so
     that rounding cannot compound: checks the orchestration (reset before/after simulate, progress
-    counting, obs/reward of the post-step state) on 48 different states including resets."""
-    n = 256
+    counting, obs/reward of the post-step state) on 48 different states including resets.  n = 8192 is the
+    bench configuration (256 workgroups, one per CU)."""
     cfg = O.default_config(n, variant)
     env = make_env(n, variant)
     seen_reset = 0
@@ -202,7 +235,10 @@ def test_fused_step_vs_oracle_resynced(variant):
         assert np.array_equal(got.reset[safe], s.reset[safe]), t
         np.testing.assert_allclose(got.root[:, :7], s.root[:, :7], rtol=2e-4, atol=2e-4)
         lin = [0, 1, 2, 3, 4, 5, 6, 10, 11]
-        np.testing.assert_allclose(got.obs[safe][:, lin], s.obs[safe][:, lin], rtol=5e-3, atol=5e-3)
+        # (velocity columns after 15 stiff substeps: 5e-3 holds for all but a few in 10^5 values -- at 8192 envs x 48 steps
+        # the tail shows: at most 1 in 10^4 may exceed it, none 2e-2)
+        dv = np.abs(got.obs[safe][:, lin] - s.obs[safe][:, lin]) - 5e-3 * np.abs(s.obs[safe][:, lin])
+        assert (dv > 5e-3).mean() <= (1e-4 if n > 1024 else 0.0) and dv.max() < 2e-2, (t, float(dv.max()), float((dv > 5e-3).mean()))
         for col in (7, 8, 9, 66):                           # angles live on a circle: 0 == 2*pi
             dang = np.abs((got.obs[safe][:, col] - s.obs[safe][:, col] + np.pi) % (2 * np.pi) - np.pi)
             assert dang.max() < 5e-3, (t, col, dang.max())

@@ -389,3 +389,33 @@ def test_failed_fused_launch_is_refused_on_the_device_and_redone():
     finally:
         lib.flyhip_debug_set_fwd_bwd_consumer_shift(0)
         os.environ.pop("FLY_FWD_BWD_HANDOFF", None)
+
+
+@pytest.mark.parametrize("mode", ["self_norm", "norm_ready", "two_launch"])
+def test_adam_refuses_a_gradient_its_producer_marked_invalid(mode):
+    """`grad_invalid` of mlp_adam_step (the err word of the peer-to-peer exchange: ANY of its workgroups sets it): nonzero ->
+    parameters, moments, fragment copies and the step counter stay exactly as they were; zero -> the step is the usual one."""
+    net, ref, pol, (x, action, old_logp, adv, target, var) = _setup(2048, 23)
+    word = torch.zeros(1, dtype=torch.int32, device=x.device)
+
+    def step():
+        pol.minibatch_grad(x, action, old_logp, adv, target, var, 0.2, fuse_norm=mode == "norm_ready")
+        pol.adam_step(norm_ready=mode == "norm_ready", self_norm=mode == "self_norm", grad_invalid=word)
+    step()
+    torch.cuda.synchronize()
+    assert int(pol.step) == 1
+    keep = [t.clone() for t in (pol.P, pol.PF, pol.PT, pol.PB, pol.exp_avg, pol.exp_avg_sq)]
+    word.fill_(1)
+    if mode != "norm_ready":            # (norm_ready: the gradient's own reduction advances the counter, as on a single rank)
+        step()
+        torch.cuda.synchronize()
+        assert int(pol.step) == 1
+    else:
+        pol.adam_step(norm_ready=True, grad_invalid=word)
+        torch.cuda.synchronize()
+    for a, b in zip(keep, (pol.P, pol.PF, pol.PT, pol.PB, pol.exp_avg, pol.exp_avg_sq)):
+        assert torch.equal(a, b)
+    word.zero_()
+    step()
+    torch.cuda.synchronize()
+    assert not torch.equal(keep[0], pol.P)

@@ -271,3 +271,44 @@ def test_replay_ring_sampling_logic():
     assert len(chunks) == 3 and all(c[0].shape == (4, 73) and c[0].data_ptr() >= rb.obs.data_ptr() for c in chunks)   # views, no copy
     big = ReplayBuffer(num_envs=32768, num_obs=73, device="meta", buffer_limit=None)
     assert big.capacity == 512 and abs(big.bytes / 1e9 - 10.0) < 0.01        # the stated default: 512 steps = 10.0 GB
+
+
+def _g2_state(g, n):
+    p = "n%d_" % n
+    s = O.EnvState(n)
+    s.obs[:] = g[p + "obs"]; s.targets[:] = g[p + "targets"]; s.root[:] = g[p + "root"]
+    s.contact[:] = g[p + "contact"]; s.pot[:] = g[p + "pot"]; s.prev_pot[:] = g[p + "prev_pot"]
+    s.progress[:] = g[p + "progress"]; s.reset[:] = g[p + "reset_in"]
+    return s
+
+
+@pytest.mark.parametrize("n", [16, 257])
+def test_reward_term_dump_is_consistent_with_the_reference_reward(golden, n):
+    """orc_reward_terms restates the viewer's P-key dump (fly.py:504-546), which no reference run can execute here (it lives in
+    the Isaac Gym viewer's event loop).  What CAN be pinned: its electricity, dof-at-limit and leg terms are the reward's own
+    (fly.py:733-744), so on g2's inputs the reference's recorded reward of every env that is not dead equals
+    0.5 + up_r * orient_r - scale * electricity_cost - dof_at_limit_cost + leg_reward with those terms -- for both cost
+    scales.  The dump's OWN up / orient terms differ from the reward's (no "below 2.1" branch, :512-513; threshold 0.92, :518,
+    against 0.98, :728): checked against their definitions, with envs inside the 0.92 .. 0.98 band present."""
+    g = golden("g2_reward")
+    s = _g2_state(g, n)
+    t = O.reward_terms(O.default_config(n), s)
+    assert set(t) == set(O.REWARD_TERMS)
+    z, ori = s.obs[:, 0], s.root[:, 5] ** 2 + s.root[:, 6] ** 2
+    up_r = np.float32(0.75) * (z > 1.4) - np.float32(0.75) * (z < 2.1)
+    orient_r = np.float32(0.75) * (ori > 0.98)
+    for tag, ecs in (("big", 0.005), ("low", 1.0)):
+        want = g["n%d_%s_reward" % (n, tag)]
+        alive = want != -2.0
+        assert alive.sum() >= 5
+        pred = 0.5 + up_r * orient_r - np.float32(ecs) * t["electricity_cost"] - t["dof_at_limit_cost"] + t["leg_reward"]
+        np.testing.assert_allclose(pred[alive], want[alive], rtol=3e-6, atol=3e-6)
+    assert np.array_equal(t["up_reward"], np.where(z > 1.4, np.float32(0.75), np.float32(0)))
+    assert np.array_equal(t["orient_reward"], np.where(ori > 0.92, np.float32(0.75), np.float32(0)))
+    band = (ori > 0.92) & (ori <= 0.98)
+    assert band.sum() >= 1 and np.all(t["orient_reward"][band] == 0.75) and np.all(orient_r[band] == 0)
+    assert np.array_equal(t["alive_reward"], np.full(n, 0.5, np.float32))
+    np.testing.assert_allclose(t["progress_reward"], s.pot - s.prev_pot, rtol=0, atol=0)
+    np.testing.assert_allclose(t["actions_cost"], (s.targets.astype(np.float64) ** 2).sum(1), rtol=2e-6)
+    hp = s.obs[:, 11]
+    np.testing.assert_allclose(t["heading_reward"], np.where(hp > 0.8, 0.5, 0.5 * hp / 0.8), rtol=2e-6, atol=1e-7)

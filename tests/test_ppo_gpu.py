@@ -179,29 +179,41 @@ def test_graph_replay_matches_eager_rollout():
                 assert a == b, (mode, i)
 
 
-def test_one_launch_per_rollout_in_training_mode():
+@pytest.mark.parametrize("n,fs", [(4096, None), (8192, None), (16384, None), (300, None), (4096, "0"), (8192, "0")])
+def test_one_launch_per_rollout_in_training_mode(n, fs, monkeypatch):
     """`persistent_rollout` (ppo_rollout_all) with the variance DECAYING (training mode, 1e-5 per step) over two whole
     iterations, updates included, with the score print (and its bookkeeping flush) landing inside rollouts while the device
-    has run ahead: rollout tensors, action_var and every parameter equal the eager run bit for bit."""
+    has run ahead: rollout tensors, per-step reset / progress rows, action_var and every parameter equal the eager run bit for
+    bit.  8192 envs = one workgroup per CU = the bench configuration (rollout_all_fs_kernel); 16384 envs walks two tiles per
+    workgroup; 300 envs has a ragged last tile (rollout_all_kernel<true> with its HBM hand-offs for that tile);
+    FLY_ROLLOUT_FS=0 forces rollout_all_kernel<true> (LDS hand-offs x_tile_lds / act_tile_lds, resident biases) at whole tiles."""
     from fly_bproject_amd.ppo import PPO
+    if fs is not None:
+        monkeypatch.setenv("FLY_ROLLOUT_FS", fs)
     res = {}
     for persistent in (False, True):
         torch.manual_seed(0)
         buf = io.StringIO()
         with contextlib.redirect_stdout(buf):
-            agent = PPO(make_args(4096, persistent_rollout=persistent))
-            T = agent.rollout_size                      # 160: the prints at run_step 100, 200, 300 fall inside rollouts
-            for _ in range(2 * T + 37):
+            agent = PPO(make_args(n, persistent_rollout=persistent))
+            assert agent.persistent_rollout == persistent
+            T = agent.rollout_size                      # 4096 envs: 160 -- the prints at run_step 100, 200, 300 fall inside rollouts
+            iters = 2 if T <= 160 else 1
+            flags = []
+            for i in range(iters * T + 37):
                 agent.run()
+                if i >= iters * T:                      # the flags run() shows for THIS step (fly.py:175-177)
+                    flags.append((agent.env.reset_buf.clone(), agent.env.progress_buf.clone()))
             agent.flush_log()
         torch.cuda.synchronize()
-        assert agent.optim_step == 150
+        assert agent.optim_step == 75 * ((iters * T + 37) // T)
         res[persistent] = (agent._obs_ring[:38].clone(), agent.all_acts[:37].clone(), agent.all_reward[:37].clone(),
                            agent.all_log_prob[:37].clone(), agent._v_ring[:37].clone(), float(agent.action_var[0]),
                            agent.policy.P.clone(), agent.policy.exp_avg_sq.clone(), agent.all_advantage.clone(),
-                           [ln for ln in buf.getvalue().splitlines() if ln.startswith("Steps:")])
+                           [ln for ln in buf.getvalue().splitlines() if ln.startswith("Steps:")],
+                           torch.stack([f[0] for f in flags]), torch.stack([f[1] for f in flags]))
         agent.exit()
-    assert abs(res[False][5] - (0.2 - (2 * 160 + 37) * 1e-5)) < 1e-6
+    assert abs(res[False][5] - (0.2 - (iters * T + 37) * 1e-5)) < 1e-6 + 2e-9 * (iters * T + 37)    # fp32 running subtraction
     for i, (a, b) in enumerate(zip(res[False], res[True])):
         if torch.is_tensor(a):
             assert torch.equal(a, b), i
@@ -411,3 +423,31 @@ def test_asynchronous_log_queue_writes_the_same_lines_in_the_same_order():
     assert res[True][0] == res[False][0] and len(res[True][0]) == 5 and res[True][0].count("Training") == 1
     assert res[True][0][-1].startswith("Steps: 0300 | Opt Step: 0075")
     assert res[True][2] == res[False][2] == 75 and torch.equal(res[True][1], res[False][1])
+
+
+def test_log_throughput_flag_extends_the_score_line_only_when_asked():
+    """`log_throughput` (trainer.py --log_throughput): every score line (ppo.py:257-260) gets ' | Env-steps/s <rate>' appended
+    (the first one 'n/a': no earlier line to measure from); without the flag stdout is the reference's text.  Same training."""
+    import re
+    from fly_bproject_amd.ppo import PPO
+    res = {}
+    for flag in (False, True):
+        torch.manual_seed(0)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            agent = PPO(make_args(2048, log_throughput=flag))
+            for _ in range(agent.rollout_size + 5):
+                agent.run()
+            agent.flush_log()
+        torch.cuda.synchronize()
+        res[flag] = ([ln for ln in buf.getvalue().splitlines() if ln.startswith("Steps:")], agent.policy.P.clone())
+        agent.exit()
+    plain, timed = res[False][0], res[True][0]
+    assert len(plain) == len(timed) >= 3
+    assert all("Env-steps/s" not in ln for ln in plain)
+    assert timed[0].endswith(" | Env-steps/s n/a")
+    for a, b in zip(plain, timed):
+        assert b.startswith(a + " | Env-steps/s ")
+    rates = [float(re.search(r"Env-steps/s ([0-9.e+]+)$", ln).group(1)) for ln in timed[1:]]
+    assert all(r > 1e5 for r in rates), rates
+    assert torch.equal(res[False][1], res[True][1])

@@ -1,0 +1,130 @@
+// What bounds a chain GEMM of mlp_fused_step.inc (fs_gemm) -- and can LDS-fed MFMAs ride in its slack?
+// One 256-thread workgroup per CU (one wave per SIMD), every CU streaming the SAME weight table from L2 as the fused step does:
+// per k-step a wave loads its 3 KiB of weight term planes (3 x global_load_dwordx4 per lane, ring of RING k-steps in flight),
+// reads three activation fragments from LDS (ds_read_b128) and issues the six MFMAs of the bf16x3 product (2 into `hi`,
+// 4 into `lo`: fs_gemm's order).  EXTRA = independent MFMAs per k-step on operands that are already in registers / come from
+// LDS only (the dW products of the fused step: their own accumulator, their own ds_reads), slotted between the chain's MFMAs.
+// Prints shader cycles per k-step: chain alone (L1-bound? 192 = six MFMAs), chain + EXTRA (free while the sum stays flat),
+// and the same chain with the weights held in registers (no stream: the MFMA-only floor with the same LDS reads).
+//   hipcc --offload-arch=gfx950 -O3 -o mfma_chain_interleave tools/mfma_chain_interleave.hip && ./mfma_chain_interleave
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Frag3 { float4 p[3]; };
+__device__ __forceinline__ bf16x8 as_b(const float4& v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ void mf(f32x16& acc, const bf16x8& a, const bf16x8& b)
+{
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
+constexpr int KSTEPS = 16;          // K = 256: layer 2 of the policy
+constexpr int PITCH = 256;          // bf16 elements per LDS row
+
+template <int EXTRA, bool STREAM, int RING>
+__global__ __launch_bounds__(256, 1) void k(const uint16_t* __restrict__ W, unsigned long long* out, int gemms, float seed)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];          // three planes [32][PITCH]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 3 * 32 * PITCH; i += 256) lds[i] = (uint16_t)(0x3c00 + (i & 63));
+    __syncthreads();
+    f32x16 hi, lo, ex[2];
+    for (int i = 0; i < 16; ++i) { hi[i] = 0.f; lo[i] = 0.f; ex[0][i] = 0.f; ex[1][i] = 0.f; }
+    const uint16_t* arow = lds + (lane & 31) * PITCH + (lane >> 5) * 8;
+    // weights: [k-step][wave][plane][lane * 8 halves]
+    const uint16_t* bp = W + (long)wave * 1536 + lane * 8;
+    Frag3 b[RING], a[2];
+    auto wload = [&](Frag3& f, int kb) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) f.p[p] = *reinterpret_cast<const float4*>(bp + (long)kb * 4 * 1536 + p * 512);
+    };
+    auto aload = [&](Frag3& f, int kb) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) f.p[p] = *reinterpret_cast<const float4*>(arow + 16 * kb + p * 32 * PITCH);
+    };
+    Frag3 e0, e1;                    // operands of the extra (dW-like) products: read from LDS per k-step
+    if (!STREAM) {
+#pragma unroll
+        for (int s = 0; s < RING; ++s) wload(b[s], s);
+    }
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int g = 0; g < gemms; ++g) {
+        if (STREAM) {
+#pragma unroll
+            for (int s = 0; s < RING; ++s) wload(b[s], s);
+        }
+        aload(a[0], 0); aload(a[1], 1);
+#pragma unroll
+        for (int kb = 0; kb < KSTEPS; ++kb) {
+            const int s = kb % RING, sa = kb & 1;
+            __builtin_amdgcn_sched_barrier(0);
+            if (EXTRA > 0) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    e0.p[p] = *reinterpret_cast<const float4*>(arow + 16 * ((kb + 5) & 15) + p * 32 * PITCH);
+                    if (EXTRA > 3) e1.p[p] = *reinterpret_cast<const float4*>(arow + 16 * ((kb + 9) & 15) + p * 32 * PITCH);
+                }
+            }
+            const bf16x8 w0 = as_b(b[s].p[0]), w1 = as_b(b[s].p[1]), w2 = as_b(b[s].p[2]);
+            const bf16x8 x0 = as_b(a[sa].p[0]), x1 = as_b(a[sa].p[1]), x2 = as_b(a[sa].p[2]);
+            mf(lo, w0, x2); mf(hi, w0, x0);
+            if (EXTRA >= 1) mf(ex[0], as_b(e0.p[0]), as_b(e0.p[2]));
+            mf(lo, w2, x0); mf(lo, w1, x1);
+            if (EXTRA >= 2) mf(ex[0], as_b(e0.p[2]), as_b(e0.p[0]));
+            if (EXTRA >= 3) mf(ex[0], as_b(e0.p[1]), as_b(e0.p[1]));
+            mf(lo, w0, x1); mf(lo, w1, x0);
+            if (EXTRA >= 4) mf(ex[1], as_b(e1.p[0]), as_b(e1.p[1]));
+            if (EXTRA >= 5) mf(ex[1], as_b(e1.p[1]), as_b(e1.p[0]));
+            if (EXTRA >= 6) mf(ex[1], as_b(e1.p[0]), as_b(e1.p[0]));
+            __builtin_amdgcn_sched_barrier(0);
+            if (STREAM && kb + RING < KSTEPS) wload(b[s], kb + RING);
+            if (kb + 2 < KSTEPS) aload(a[sa], kb + 2);
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(hi), "+v"(lo));
+    asm volatile("s_nop 7" : "+v"(ex[0]), "+v"(ex[1]));
+    float sum = seed;
+    for (int i = 0; i < 16; ++i) sum += hi[i] + lo[i] + ex[0][i] + ex[1][i];
+    if (tid == 0) out[blockIdx.x] = t1 - t0;
+    if (sum == 12345.678f) out[0] = 0;
+}
+
+template <int EXTRA, bool STREAM, int RING>
+double run(const uint16_t* W)
+{
+    const int wgs = 256, gemms = 400;
+    unsigned long long* out;
+    (void)hipMalloc(&out, wgs * 8);
+    const size_t ldsb = 3 * 32 * PITCH * 2;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k<EXTRA, STREAM, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    hipLaunchKernelGGL((k<EXTRA, STREAM, RING>), dim3(wgs), dim3(256), ldsb, 0, W, out, 20, 1.0f);
+    hipLaunchKernelGGL((k<EXTRA, STREAM, RING>), dim3(wgs), dim3(256), ldsb, 0, W, out, gemms, 1.0f);
+    (void)hipDeviceSynchronize();
+    unsigned long long h[256];
+    (void)hipMemcpy(h, out, sizeof h, hipMemcpyDeviceToHost);
+    double mean = 0;
+    for (int i = 0; i < wgs; ++i) mean += (double)h[i];
+    mean /= wgs;
+    (void)hipFree(out);
+    const double per = mean / (gemms * (double)KSTEPS);
+    printf("%s weights, ring %d, %d extra LDS-fed MFMAs per k-step: %6.1f cycles per k-step = %5.1f per MFMA (%d MFMAs)\n",
+           STREAM ? "streamed  " : "registered", RING, EXTRA, per, per / (6 + EXTRA), 6 + EXTRA);
+    return per;
+}
+
+int main()
+{
+    uint16_t* W;
+    const size_t halves = (size_t)KSTEPS * 4 * 1536;            // 196 KiB: layer 2's term planes
+    (void)hipMalloc(&W, halves * 2);
+    (void)hipMemset(W, 0x3c, halves * 2);
+    run<0, false, 4>(W); run<3, false, 4>(W); run<6, false, 4>(W);
+    run<0, true, 4>(W); run<1, true, 4>(W); run<2, true, 4>(W); run<3, true, 4>(W); run<4, true, 4>(W); run<6, true, 4>(W);
+    run<0, true, 6>(W); run<3, true, 6>(W);
+    run<0, true, 2>(W);
+    (void)hipFree(W);
+    return 0;
+}

@@ -11,7 +11,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from bench import make_args  # noqa: E402
+from bench import RolloutAllHarness, make_args  # noqa: E402
 from fly_bproject_amd import _lib  # noqa: E402
 from fly_bproject_amd.fly import Fly  # noqa: E402
 from fly_bproject_amd.policy import PackedPolicy  # noqa: E402
@@ -48,6 +48,13 @@ with torch.no_grad():
     for _ in range(REPS):
         pol.forward(xs, want_mu=True, want_v=False)
 torch.cuda.synchronize()
+# the loop's rollout: ONE launch for the T steps of every tile (rollout_all_fs_kernel at 8192 envs; PROF_T steps per launch)
+T_ROLL = int(os.environ.get("PROF_T", str(16 * (40960 // N))))
+harness = RolloutAllHarness(env, pol, T_ROLL, var)
+for _ in range(max(2, REPS // 4)):
+    harness.launch()
+torch.cuda.synchronize()
+del harness
 env.exit()
 if os.environ.get("PROF_DQN", "1") != "0":          # configs[4]: one sampled replay step of 32768 rows through the DQN kernels
     from fly_bproject_amd.dqn import DQN

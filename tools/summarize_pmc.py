@@ -23,7 +23,7 @@ WIDE_READS = ("mlp_fused_step_kernel", "mlp_forward_kernel", "mlp_backward_dx_ke
 
 
 def short(name):
-    m = re.search(r"(fly_kernel<\d+>|mlp_\w+_kernel|ppo_\w+_kernel|dqn_\w+_kernel|rollout_step_kernel)", name)
+    m = re.search(r"(fly_kernel<\d+>|mlp_\w+_kernel|ppo_\w+_kernel|dqn_\w+_kernel|rollout_step_kernel|rollout_all_fs_kernel|rollout_all_kernel)", name)
     return m.group(1) if m else None
 
 
@@ -64,6 +64,32 @@ def main():
     with open(os.path.join(out_dir, "%s_traffic.json" % tag), "w") as fo:
         json.dump(traffic, fo, indent=1, sort_keys=True)
     print(json.dumps(traffic, indent=1, sort_keys=True))
+    # vector instructions per wave of the env kernels (bench.py's `valu_roofline` reads the newest *_valu.json)
+    valu = {}
+    bench_grid = int(os.environ.get("PROF_ENVS", "8192")) // 32 * 256        # the entry of the bench size wins over other sizes
+    for (k, g, c), v in sorted(agg.items(), key=lambda kv: kv[0][1] == bench_grid):
+        if c == "SQ_INSTS_VALU" and (k.startswith("fly_kernel<63>") or k.startswith("rollout_all")):
+            waves = agg.get((k, g, "SQ_WAVES"))
+            if waves:
+                w = sum(waves) / len(waves)
+                e = {"valu_insts_per_wave": int(round(sum(v) / len(v) / w)), "sq_insts_valu_per_launch": sum(v) / len(v), "waves": int(w),
+                     "grid_threads": g}
+                for extra in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY"):
+                    x = agg.get((k, g, extra))
+                    if x:
+                        e[extra.lower() + "_per_launch"] = sum(x) / len(x)
+                valu[k] = e
+    if valu:
+        steps = int(os.environ.get("PROF_T", "80"))
+        for k, e in valu.items():
+            if k.startswith("rollout_all"):
+                e["env_steps_per_launch"] = steps
+                e["valu_insts_per_wave_per_env_step"] = int(round(e["valu_insts_per_wave"] / steps))
+        valu["clock_ghz"] = 2.1
+        valu["source"] = "rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU -- python3 tools/prof_kernels.py (tools/collect_profiles.sh %s)" % tag
+        with open(os.path.join(out_dir, "%s_valu.json" % tag), "w") as fo:
+            json.dump(valu, fo, indent=1, sort_keys=True)
+        print(json.dumps(valu, indent=1, sort_keys=True))
 
 
 if __name__ == "__main__":

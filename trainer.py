@@ -5,7 +5,7 @@ Same flags (`--sim_device --compute_device_id --graphics_device_id --num_envs --
 --time_steps_per_recorded_frame --testing`), same seeding and the same run loop.  Additions:
 `--rl_device` (accepted alias; the reference uses sim_device for both), `--variant`
 (bigGrav = fly.py, lowGrav = flyLowGrav.py), `--reward` (standing | walking), `--max_steps`
-(bounded runs; the reference loops until the viewer's E key) and `--seed`.
+(bounded runs; the reference loops until the viewer's E key), `--seed` and `--log_throughput` (env-steps/s on the score line).
 Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N trainer.py ...`;
 each rank owns `--num_envs` envs on its own GPU.
 """
@@ -37,8 +37,13 @@ def parse_args(argv=None):
     parser.add_argument('--max_steps', type=int, default=0, help='stop after this many env steps (0 = run until env.end)')
     parser.add_argument('--seed', type=int, default=0)
     parser.add_argument('--gemm', type=str, default=None, choices=["f32", "bf16x3"],
-                        help='arithmetic of the update\'s forward/dX GEMMs: fp32 MFMA (default) or three-term bf16 operand '
-                             'splits on the bf16 matrix pipe (fp32-accurate, DESIGN.md 3.4); default: $FLY_GEMM or f32')
+                        help='arithmetic of EVERY MLP GEMM (rollout policy, critic pass, the update): bf16x3 (default) = fp32 '
+                             'operands split exactly into three bf16 terms on the bf16 matrix pipe, fp32 accumulate (held to the '
+                             'reference goldens at the fp32 tolerances, DESIGN.md 3.4); f32 = v_mfma_f32_32x32x2_f32.  '
+                             'Default: $FLY_GEMM or bf16x3')
+    parser.add_argument('--log_throughput', action='store_true',
+                        help='append env-steps/s (all ranks, host clock, since the previous score line) to the score line '
+                             '(ppo.py:257-260 prints the score only; off by default so that stdout stays the reference\'s)')
     parser.add_argument('--dp_mode', type=str, default="grad_allreduce", choices=["grad_allreduce", "param_average"],
                         help='multi-GPU: all-reduce the gradient every optimizer step (reference algorithm on the global '
                              'batch) or average parameters once per PPO update (non-parity)')
