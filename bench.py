@@ -855,7 +855,8 @@ def main():
     update_path = agent.policy.update_path()
     p2p_selftest = getattr(agent, "p2p_selftest", None)
     used_exchange = agent.dp_allreduce
-    agent.exit()
+    with quiet():
+        agent.exit()                                 # (flushes the score lines still queued: they must not reach the JSON's stdout)
     del agent
     torch.cuda.empty_cache()
 

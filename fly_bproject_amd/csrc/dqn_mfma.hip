@@ -441,7 +441,7 @@ extern "C" hipError_t flyhip_launch_dqn_grad_w(const float* x, const float* h1, 
     for (int l = 0; l < 3; ++l) {
         T.l[l].dz = dz[l]; T.l[l].a = a[l]; T.l[l].partial = ws;
         T.l[l].N = N[l]; T.l[l].Ka = Ka[l]; T.l[l].KP = KP[l]; T.l[l].wgs = kDqnGradWgs[l]; T.l[l].first_block = first;
-        T.l[l].accumulate = accumulate & 1;
+        T.l[l].accumulate = accumulate & 1; T.l[l].chunked = 0;
         ws += (long)kDqnGradWgs[l] * ((long)N[l] * KP[l] + N[l]);
         first += kDqnGradWgs[l];
     }

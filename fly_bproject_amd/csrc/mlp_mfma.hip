@@ -428,7 +428,7 @@ extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, 
     for (int l = 0; l < 4; ++l) {
         T.l[l].dz = dz[l]; T.l[l].a = a[l]; T.l[l].partial = ws;
         T.l[l].N = N[l]; T.l[l].Ka = Ka[l]; T.l[l].KP = KP[l]; T.l[l].wgs = wgs[l]; T.l[l].first_block = first;
-        T.l[l].accumulate = 0;
+        T.l[l].accumulate = 0; T.l[l].chunked = 0;
         ws += (long)wgs[l] * ((long)N[l] * KP[l] + N[l]);
         first += wgs[l];
     }
@@ -491,7 +491,8 @@ static int fused_grid(int64_t n)
 
 extern "C" int64_t flyhip_mlp_fused_workspace_floats(void)
 {
-    return (int64_t)fused_cus() * MLP_PACKED_FLOATS;            // one partial slab per workgroup
+    // one partial slab per workgroup; chunked layout: every layer's block padded to whole 1 KiB chunks
+    return (int64_t)fused_cus() * (fs_pad256(FS_STRIDE1) + fs_pad256(FS_STRIDE2) + fs_pad256(FS_STRIDE3) + fs_pad256(FS_STRIDE4));
 }
 
 extern "C" hipError_t flyhip_launch_mlp_fused_grad(const float* P, const uint16_t* PB, const uint16_t* PTB, const float* x,
@@ -530,7 +531,9 @@ extern "C" hipError_t flyhip_launch_mlp_fused_grad(const float* P, const uint16_
     for (int l = 0; l < 4; ++l) {
         T.l[l].dz = nullptr; T.l[l].a = nullptr; T.l[l].partial = w;
         T.l[l].N = N[l]; T.l[l].Ka = KP[l]; T.l[l].KP = KP[l]; T.l[l].wgs = grid; T.l[l].first_block = 0; T.l[l].accumulate = 0;
-        w += (long)grid * ((long)N[l] * KP[l] + N[l]);
+        T.l[l].chunked = FS_SLAB_CHUNKED;
+        const long stride = (long)N[l] * KP[l] + N[l];
+        w += (long)grid * (FS_SLAB_CHUNKED ? fs_pad256(stride) : stride);
     }
     // (loads in flight per wave: 4 -> 15.8 us for the 256 slabs, 8 -> 17.2, 16 -> 58 (the 1024-thread block's register budget))
     hipLaunchKernelGGL(mlp_grad_reduce_kernel<4>, dim3(RED_BLOCKS), dim3(64 * RED_WAVES), 0, (hipStream_t)stream, T, grad_out,

@@ -21,7 +21,7 @@ __device__ __forceinline__ void mf(f32x16& acc, const bf16x8& a, const bf16x8& b
 }
 
 constexpr int KSTEPS = 16;          // K = 256: layer 2 of the policy
-constexpr int PITCH = 256;          // bf16 elements per LDS row
+constexpr int PITCH = 264;          // bf16 elements per LDS row (K + 8: conflict-free ds_read_b128, as tile_gemm_b3)
 
 template <int EXTRA, bool STREAM, int RING>
 __global__ __launch_bounds__(256, 1) void k(const uint16_t* __restrict__ W, unsigned long long* out, int gemms, float seed)
