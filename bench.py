@@ -233,7 +233,7 @@ class RolloutAllHarness:
         C = self.C
         p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
         wgs = (self.n + 31) // 32
-        stamps = torch.zeros(wgs, self.T + 1, 2, dtype=torch.int64, device="cuda:0")
+        stamps = torch.zeros(wgs, self.T + 1, 8, dtype=torch.int64, device="cuda:0")
         fn = self.lib.flyhip_debug_rollout_all_stamped
         fn.restype = C.c_int
         fn.argtypes = [C.c_void_p, C.c_void_p] + [C.c_void_p] * 5 + [C.c_float, C.c_float] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 5
@@ -244,13 +244,18 @@ class RolloutAllHarness:
             return None
         self._chain()
         torch.cuda.synchronize()
-        s = stamps.cpu().numpy()
-        top, mid = s[:, :, 0], s[:, :-1, 1]
-        pol_c = (mid[:, 1:] - top[:, 1:-1]).astype("float64")
-        env_c = (top[:, 2:] - mid[:, 1:]).astype("float64")
+        s = stamps.cpu().numpy().astype("float64")
+        top, mid = s[:, :, 0], s[:, :-1, 7]
+        pol_c = mid[:, 1:] - top[:, 1:-1]
+        env_c = top[:, 2:] - mid[:, 1:]
         tot = pol_c.mean() + env_c.mean()
+        inner = s[:, 1:-1, :]                # steps 1 .. T-1: [x converted, L1, L2, L3, L4 done] relative to the step's top, then sampling
+        marks = [inner[:, :, k] - inner[:, :, k - 1] if k > 1 else inner[:, :, 1] - inner[:, :, 0] for k in range(1, 6)]
+        marks.append(inner[:, :, 7] - inner[:, :, 5])
+        names = ("x_convert", "layer1", "layer2", "layer3", "layer4_splitk", "outputs_sampling")
         return {"policy_frac": float(pol_c.mean() / tot), "env_frac": float(env_c.mean() / tot),
-                "policy_cycles": float(pol_c.mean()), "env_cycles": float(env_c.mean())}
+                "policy_cycles": float(pol_c.mean()), "env_cycles": float(env_c.mean()),
+                "policy_sub_cycles": {nm: float(m.mean()) for nm, m in zip(names, marks)}}
 
 
 def mlp_peak_for(gemm):
@@ -372,6 +377,7 @@ def kernel_rooflines(num_envs, T, reps, gemm="f32"):
             "source": "s_memtime stamps of the diagnostic instantiation (all workgroups, steps 1..T-1), shares applied to the HIP-event time",
             "policy_us_per_step": round(pol_us, 3), "env_us_per_step": round(env_us, 3),
             "policy_frac": round(split["policy_frac"], 4), "env_frac": round(split["env_frac"], 4),
+            "policy_sub_cycles": {k: round(v) for k, v in split.get("policy_sub_cycles", {}).items()},
             "policy_mfma": {"achieved": round(MLP_FWD_FLOP * num_envs / pol_us / 1e6, 3), "peak": mlp_peak_for(pol.gemm),
                             "unit": "TFLOP/s", "frac": round(MLP_FWD_FLOP * num_envs / pol_us / 1e6 / mlp_peak_for(pol.gemm), 5)},
             "physics_in_loop": {

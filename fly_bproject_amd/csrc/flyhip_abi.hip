@@ -255,7 +255,7 @@ int ppo_rollout_all(FlyHandle h, const FlyBuffers* b, const float* params, const
 }
 
 // diagnostic: the same launch through the stamped instantiation of rollout_all_fs_kernel (bench.py's policy / env split of a
-// rollout step, tools/stamp_rollout.py); stamps u64 [workgroups][T + 1][2].  Not part of the ABI header.
+// rollout step, tools/ab_rollout.py); stamps u64 [tiles][T + 1][8].  Not part of the ABI header.
 extern "C" int flyhip_debug_rollout_all_stamped(FlyHandle h, const FlyBuffers* b, const float* params, const float* params_frag,
                                                 float* obs_ring, const float* eps_all, const float* var, float var_decay,
                                                 float var_min, float* act_all, float* logp_all, float* v_ring, float* reward_all,

@@ -142,8 +142,12 @@ __global__ __launch_bounds__(THREADS, WPS) void rollout_all_kernel(
 // The same loop with the policy in the fused step's style (policy_tile_fs, mlp_fused_step.inc): swizzled plane images, the chain
 // GEMMs' asm MFMA streams, 135 KB of LDS -- one workgroup per CU, whole tiles only (the launcher checks both).  The env step
 // stages its observation block in H2's region of that image, which is where the next step's policy converts it from.
-// STAMP (diagnostic instantiation, bench.py / tools/stamp_rollout.py): thread 0 of every workgroup stores s_memtime at the top of
-// each step and between its policy and env halves into stamps u64 [workgroup][T + 1][2] (+ the 100 MHz real-time counter once).
+// STAMP (diagnostic instantiation, bench.py / tools/ab_rollout.py): thread 0 of every workgroup stores s_memtime into stamps
+// u64 [tile][T + 1][8]: slot 0 the top of step t, 1 .. 5 inside the policy (x converted, layer 1, 2, 3, 4 done), 7 between the
+// policy and env halves (+ the 100 MHz real-time counter once, at [T][1]).
+#ifndef FR_HOIST
+#define FR_HOIST 1          // layer 1's first weights of the NEXT step are requested before the env step (A/B: 0)
+#endif
 // MULTI: more tiles than workgroups (> 8192 envs on 256 CUs): the outer loop really loops; the single-tile instantiation keeps
 // the register allocation of a kernel without it.
 template <bool STAMP, bool MULTI>
@@ -165,29 +169,33 @@ __global__ __launch_bounds__(THREADS, 1) void rollout_all_fs_kernel(
     // <= 8192 envs on 256 CUs; two at 16384).  Tiles are independent, so the order is free and every row equals the per-step launches'.
     long tile = blockIdx.x;
     do {
-        unsigned long long* st_tile = STAMP ? stamps + tile * (T + 1) * 2 : nullptr;
+        unsigned long long* st_tile = STAMP ? stamps + tile * (T + 1) * 8 : nullptr;
         if (threadIdx.x < 32) L.varcur[threadIdx.x] = threadIdx.x < MLP_NACT ? var[threadIdx.x] : 1.0f;   // the variance of row 0 (see rollout_all_kernel)
         b.reset = reset0; b.progress = progress0;
         FlyRegs st;
         fly_load<PH_ALL>(st, c, b, (int)tile);
+        FrHead w1;
+        policy_tile_fs_head(w1, PB);
         __syncthreads();
         for (int t = 0; t < T; ++t) {
-            stamp<STAMP>(st_tile, 2 * t);
+            stamp<STAMP>(st_tile, 8 * t);
             float* act = act_all + (long)t * n * MLP_NACT;
             b.obs = obs_ring + (long)(t + 1) * n * FLY_NUM_OBS;
             b.reward = reward_all + (long)t * n;
             if (reset_rows) { b.reset = reset_rows + (long)t * n; b.progress = progress_rows + (long)t * n; }   // fly.py:175-177, per step
-            policy_tile_fs(L, tile, PB, t == 0 ? obs_ring : nullptr, n, v_ring + (long)t * n, eps_all + (long)t * n * MLP_NACT, act,
-                           logp_all + (long)t * n);
-            stamp<STAMP>(st_tile, 2 * t + 1);
+            if (!FR_HOIST && t > 0) policy_tile_fs_head(w1, PB);
+            policy_tile_fs<STAMP>(L, tile, PB, t == 0 ? obs_ring : nullptr, n, v_ring + (long)t * n, eps_all + (long)t * n * MLP_NACT, act,
+                                  logp_all + (long)t * n, w1, STAMP ? st_tile + 8 * t : nullptr);
+            stamp<STAMP>(st_tile, 8 * t + 7);
+            if (FR_HOIST) policy_tile_fs_head(w1, PB);     // the NEXT step's first weights: their round trip hides under the physics
             FlyRegs nx;
             fly_body<PH_ALL>(c, act, b, L.obs, (int)tile, st, &nx, L.acts);
             st = nx;
             if (threadIdx.x < MLP_NACT && var_decay > 0.0f) L.varcur[threadIdx.x] = fmaxf(var_min, L.varcur[threadIdx.x] - var_decay);
             __syncthreads();
         }
-        stamp<STAMP>(st_tile, 2 * T);
-        if (STAMP && threadIdx.x == 0) st_tile[2 * T + 1] = realtime_cu();
+        stamp<STAMP>(st_tile, 8 * T);
+        if (STAMP && threadIdx.x == 0) st_tile[8 * T + 1] = realtime_cu();
         tile += gridDim.x;
     } while (MULTI && tile < ntiles);
 }
