@@ -244,7 +244,11 @@ class RolloutAllHarness:
             return None
         self._chain()
         torch.cuda.synchronize()
-        s = stamps.cpu().numpy().astype("float64")
+        raw = stamps.cpu().numpy()
+        mask = (1 << 48) - 1
+        rt = ((raw[:, self.T, 1] & mask) - (raw[:, 0, 6] & mask)).astype("float64") * 10e-9        # 100 MHz real-time counter
+        clock_ghz = float(((raw[:, self.T, 0] - raw[:, 0, 0]).astype("float64") / rt).mean() / 1e9)
+        s = raw.astype("float64")
         top, mid = s[:, :, 0], s[:, :-1, 7]
         pol_c = mid[:, 1:] - top[:, 1:-1]
         env_c = top[:, 2:] - mid[:, 1:]
@@ -254,7 +258,7 @@ class RolloutAllHarness:
         marks.append(inner[:, :, 7] - inner[:, :, 5])
         names = ("x_convert", "layer1", "layer2", "layer3", "layer4_splitk", "outputs_sampling")
         return {"policy_frac": float(pol_c.mean() / tot), "env_frac": float(env_c.mean() / tot),
-                "policy_cycles": float(pol_c.mean()), "env_cycles": float(env_c.mean()),
+                "policy_cycles": float(pol_c.mean()), "env_cycles": float(env_c.mean()), "clock_ghz": clock_ghz,
                 "policy_sub_cycles": {nm: float(m.mean()) for nm, m in zip(names, marks)}}
 
 
@@ -363,7 +367,7 @@ def kernel_rooflines(num_envs, T, reps, gemm="f32"):
                 "avg_launch_us": round(dur * 1e6, 3), "algorithmic_per_launch": flop_per_launch,
                 "launches_per_iteration": per_iter, "iteration_share_ms": round(dur * per_iter * 1e3, 3)}
 
-    fs_kernel = pol.gemm_infer == "bf16x3" and num_envs % 32 == 0 and num_envs // 32 <= torch.cuda.get_device_properties(0).multi_processor_count
+    fs_kernel = pol.gemm_infer == "bf16x3" and num_envs % 32 == 0      # (persistent over tiles beyond one tile per CU)
     roll_name = "%s (one launch per rollout: T=%d x [policy + sample + env step], %d envs)" % (
         "rollout_all_fs_kernel" if fs_kernel else "rollout_all_kernel", T, num_envs)
     roll_all = mfma(roll_name, t_all, MLP_FWD_FLOP * num_envs * T, 1)
@@ -377,6 +381,7 @@ def kernel_rooflines(num_envs, T, reps, gemm="f32"):
             "source": "s_memtime stamps of the diagnostic instantiation (all workgroups, steps 1..T-1), shares applied to the HIP-event time",
             "policy_us_per_step": round(pol_us, 3), "env_us_per_step": round(env_us, 3),
             "policy_frac": round(split["policy_frac"], 4), "env_frac": round(split["env_frac"], 4),
+            "in_kernel_clock_ghz": round(split.get("clock_ghz", 0.0), 3),
             "policy_sub_cycles": {k: round(v) for k, v in split.get("policy_sub_cycles", {}).items()},
             "policy_mfma": {"achieved": round(MLP_FWD_FLOP * num_envs / pol_us / 1e6, 3), "peak": mlp_peak_for(pol.gemm),
                             "unit": "TFLOP/s", "frac": round(MLP_FWD_FLOP * num_envs / pol_us / 1e6 / mlp_peak_for(pol.gemm), 5)},
@@ -424,10 +429,13 @@ def kernel_rooflines(num_envs, T, reps, gemm="f32"):
                                           "waves_per_simd": 1, "clock_ghz": clk, "floor_us": round(floor_us, 2),
                                           "frac": round(floor_us / (t_step * 1e6), 4), "source": os.path.basename(vf[-1])}
                 ph = k.get("phases")
-                if ph:      # the same body as the env half of a rollout step: its instruction count against the half's time
+                if ph:      # the same body as the env half of a rollout step: its instruction count against the half's time,
+                    # at the clock the rollout kernel itself runs at (measured by its stamps)
+                    clk_in = ph.get("in_kernel_clock_ghz") or clk
+                    fl = ipw * 4 / (clk_in * 1e3)
                     ph["physics_in_loop"]["valu_roofline"] = {
                         "bound": "valu-issue", "valu_insts_per_wave": ipw, "issue_cycles_per_inst": 4, "waves_per_simd": 1,
-                        "clock_ghz": clk, "floor_us": round(floor_us, 2), "frac": round(floor_us / ph["env_us_per_step"], 4),
+                        "clock_ghz": clk_in, "floor_us": round(fl, 2), "frac": round(fl / ph["env_us_per_step"], 4),
                         "source": os.path.basename(vf[-1])}
     except Exception:
         pass

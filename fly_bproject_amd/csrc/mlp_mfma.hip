@@ -177,6 +177,7 @@ __global__ __launch_bounds__(THREADS, 1) void rollout_all_fs_kernel(
         FrHead w1;
         policy_tile_fs_head(w1, PB);
         __syncthreads();
+        if (STAMP && threadIdx.x == 0) st_tile[6] = realtime_cu();      // (with [T][1]: the shader clock the stamps tick at)
         for (int t = 0; t < T; ++t) {
             stamp<STAMP>(st_tile, 8 * t);
             float* act = act_all + (long)t * n * MLP_NACT;
