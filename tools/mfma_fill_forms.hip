@@ -9,7 +9,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // filler kinds: 0 v_fma_f32, 1 v_pk_add_f32, 2 v_exp_f32, 3 v_cvt_pk_bf16_f32, 4 v_cmp + v_cndmask (counted as two), 5 ds_write_b64,
-// 6 v_lshlrev + v_and (bf16 pair -> two floats)
+// 6 v_lshlrev + v_and (bf16 pair -> two floats), 7 v_fma_f32 as ONE dependent chain (every filler of a gap reads the previous one's
+// result: what an epilogue slice looks like), 8 two interleaved dependent chains
 template <int F, bool AGPR, int KIND = 0>
 __global__ __launch_bounds__(256) void k(unsigned long long* out, int iters, float a)
 {
@@ -42,6 +43,8 @@ __global__ __launch_bounds__(256) void k(unsigned long long* out, int iters, flo
                 if (KIND == 4 && (j & 1) == 0) asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\ts_nop 1\n\tv_cndmask_b32 %0, %1, %2, vcc" : "+v"(v[j & 7]) : "v"(b), "v"(a) : "vcc");
                 if (KIND == 5) asm volatile("ds_write_b64 %0, %1" : : "v"((threadIdx.x * 8 + 2048 * (j & 3)) & 16383), "v"(pk[j & 3]) : "memory");
                 if (KIND == 6) asm volatile("v_lshlrev_b32 %0, 16, %2\n\tv_and_b32 %1, 0xffff0000, %2" : "=v"(w[j & 3]), "=v"(w[(j + 1) & 3]) : "v"(v[j & 7]));
+                if (KIND == 7) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[0]) : "v"(b), "v"(a));
+                if (KIND == 8) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[j & 1]) : "v"(b), "v"(a));
             }
         }
     }
@@ -70,7 +73,8 @@ void run()
     double mean = 0;
     for (int i = 0; i < wgs; ++i) mean += (double)h[i];
     mean /= wgs;
-    static const char* kinds[] = {"v_fma_f32", "v_pk_add_f32", "v_exp_f32", "v_cvt_pk_bf16_f32", "(v_cmp + s_nop 1 + v_cndmask)/2", "ds_write_b64", "v_lshlrev + v_and"};
+    static const char* kinds[] = {"v_fma_f32", "v_pk_add_f32", "v_exp_f32", "v_cvt_pk_bf16_f32", "(v_cmp + s_nop 1 + v_cndmask)/2", "ds_write_b64", "v_lshlrev + v_and",
+                                  "v_fma_f32 (ONE dependent chain)", "v_fma_f32 (two dependent chains)"};
     printf("accumulator in %s, %d x %s behind each MFMA: %.1f clock ticks per MFMA\n", AGPR ? "AGPRs" : "VGPRs", F, kinds[KIND], mean / (iters * 8.0));
     (void)hipFree(out);
 }
@@ -82,5 +86,7 @@ int main()
     run<4, false, 1>(); run<8, false, 1>(); run<2, false, 2>(); run<4, false, 2>(); run<4, false, 3>(); run<8, false, 3>();
     run<4, false, 4>(); run<8, false, 4>(); run<2, false, 5>(); run<4, false, 5>(); run<2, false, 6>(); run<4, false, 6>();
     run<4, true, 1>(); run<8, true, 1>(); run<4, true, 2>(); run<8, true, 3>(); run<8, true, 4>(); run<4, true, 5>(); run<4, true, 6>();
+    run<2, true, 7>(); run<3, true, 7>(); run<4, true, 7>(); run<5, true, 7>(); run<6, true, 7>(); run<8, true, 7>();
+    run<4, true, 8>(); run<6, true, 8>(); run<8, true, 8>();
     return 0;
 }

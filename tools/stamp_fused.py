@@ -27,7 +27,8 @@ for _ in range(30):
     pol.minibatch_grad(x, act, olp, adv, tgt, var, 0.2)
 torch.cuda.synchronize()
 grid = 256
-stamps = torch.zeros(grid * 64 * 16, dtype=torch.int64, device="cuda:0")
+SLOTS = 32
+stamps = torch.zeros(grid * 64 * SLOTS, dtype=torch.int64, device="cuda:0")
 p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
 arr = (C.c_void_p * 8)(stamps.data_ptr(), None, None, None, None, None, None, None)
 ws = torch.empty(int(_lib.load().mlp_fused_workspace_floats()), device="cuda:0")
@@ -36,7 +37,7 @@ for _ in range(3):
                                           C.c_float(1.0 / rows), C.c_float(0.2), p(ws), p(pol.G), None, None, None, p(pol.loss_part),
                                           arr, None), "stamp")
 torch.cuda.synchronize()
-s = stamps.cpu().numpy().reshape(grid, 64, 16).astype(np.int64)
+s = stamps.cpu().numpy().reshape(grid, 64, SLOTS).astype(np.int64)
 tiles = (rows + 31) // 32
 per = (tiles + grid - 1) // grid
 names = ["P0 x_store", "P1 L1 (2 tiles) work", "P1 barrier wait", "P2 L2", "P3 L3", "P4 L4 split-K", "P5 loss", "P6 dA3+dW4+dz3",
@@ -59,6 +60,10 @@ sub = np.array([[s[b, t, 12] - s[b, t, 9], s[b, t, 13] - s[b, t, 12], s[b, t, 14
                 for b in range(grid) for t in range(per) if s[b, t, 11] > 0])
 print("inside P8: tile 0: dA1 GEMM (48 MFMA) %.0f | x DMA issue + dW2 with the dZ1 epilogue in its gaps (48) %.0f | dW1 tile 0 (36) %.0f | tile 1: GEMM + dW2/epilogue %.0f | dW1 tile 1 %.0f"
       % tuple(sub.mean(0)))
+fine = np.array([[s[b, t, 18] - s[b, t, 12], s[b, t, 17] - s[b, t, 18], s[b, t, 13] - s[b, t, 17], s[b, t, 16] - s[b, t, 14], s[b, t, 15] - s[b, t, 16]]
+                 for b in range(grid) for t in range(per) if s[b, t, 11] > 0])
+print("   column tile 0: x DMA issue + H1/dZ2 fragment reads + dW2 c = 0..3 %.0f | c = 4..7 %.0f | fragment assembly, db2, drain, head of the second GEMM %.0f || column tile 1: GEMM %.0f | dW2 + epilogue %.0f"
+      % tuple(fine.mean(0)))
 tail = s[:, 63, 1] - s[:, 63, 0]
 print("epilogue (slab write + bias sums) per workgroup: mean %.0f cycles" % tail.mean())
 pro = s[:, 62, 2] - s[:, 62, 0]
