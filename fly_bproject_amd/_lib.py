@@ -55,7 +55,10 @@ SYMBOLS = {
     "dqn_td_step": [_P] * 10 + [_L, _F, _F] + [_P] * 7,
     "dqn_grad_workspace_floats": [],
     "dqn_grad_w": [_P] * 6 + [_L, _P, _P, _I, _P],
-    "dqn_adam_soft_update": [_P] * 12 + [_F, _F, _F, _F, _F, _P],
+    "dqn_fused_workspace_floats": [],
+    "dqn_fused_image_halves": [_L],
+    "dqn_fused_update": [_P] * 6 + [_I, _L, _F, _F, _P, _P, _P, _P, _I, _P],
+    "dqn_adam_soft_update": [_P] * 12 + [_F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P],
     "dp_p2p_alloc": [_L, C.POINTER(_P)],
     "dp_p2p_free": [_P],
     "dp_ipc_export": [_P, _P],
@@ -88,7 +91,7 @@ def load():
     for name, argtypes in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
         fn.argtypes = argtypes
-        fn.restype = C.c_int64 if name.endswith("_workspace_floats") else C.c_int
+        fn.restype = C.c_int64 if name.endswith(("_workspace_floats", "_image_halves")) else C.c_int
     _lib = lib
     return lib
 

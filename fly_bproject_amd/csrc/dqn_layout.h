@@ -37,4 +37,19 @@
 #define DQN_OFF_T2 (DQN_OFF_T3 + DQN_H * DQN_OUT)        /* 8192: W2^T 256 x 256 */
 #define DQN_FRAG_T_FLOATS (DQN_OFF_T2 + DQN_H * DQN_H)   /* 73728 */
 
+
+/* bf16x3 operand planes of the same weights (the layout of mlp_layout.h: element (n, k), term p of an operand with N outputs
+ * and K reduced at (((n/32) * (K/16) + k/16) * 3 + p) * 512 + (((k%16)/8) * 32 + n%32) * 8 + k%8 16-bit words):
+ *   QB  forward operands  W1 [256][80] | W2 [256][256] | W3 [32][256]   (the fused update's chain reads W3's k range of a wave
+ *       as the sub-operand starting at k-step 4 w: split-K needs no layout of its own here)
+ *   QTB backward operands W3^T [256 outputs][32 reduced] | W2^T [256][256]
+ * dqn_adam_soft_update maintains QB / QTB of the online network and QB of the target network. */
+#define DQN_OFF_QB1 0
+#define DQN_OFF_QB2 (DQN_OFF_QB1 + 3 * DQN_H * DQN_IN_PAD)    /*  61440 */
+#define DQN_OFF_QB3 (DQN_OFF_QB2 + 3 * DQN_H * DQN_H)         /* 258048 */
+#define DQN_QB_HALVES (DQN_OFF_QB3 + 3 * DQN_OUT * DQN_H)     /* 282624 16-bit words */
+#define DQN_OFF_QTB3 0
+#define DQN_OFF_QTB2 (DQN_OFF_QTB3 + 3 * DQN_H * DQN_OUT)     /*  24576 */
+#define DQN_QTB_HALVES (DQN_OFF_QTB2 + 3 * DQN_H * DQN_H)     /* 221184 16-bit words */
+
 #endif

@@ -23,6 +23,8 @@ namespace {
 
 #include "mlp_gemm.inc"
 #include "grad_w_layer.inc"
+#include "fs_common.inc"
+#include "dqn_fused.inc"
 
 constexpr int DQ_P = DQN_H + 4;                         // LDS pitch of a [32][256] activation tile
 constexpr int DQ_TILE = BM * DQ_P;                      // 8320 floats
@@ -357,7 +359,8 @@ __global__ __launch_bounds__(DQ_ADAM_THREADS) void dqn_adam_kernel(
     float* __restrict__ P, float* __restrict__ PF, float* __restrict__ PT, float* __restrict__ P_tgt, float* __restrict__ PF_tgt,
     const int* __restrict__ idx_f, const int* __restrict__ idx_t, const float* __restrict__ G, const float* __restrict__ mask,
     float* __restrict__ m, float* __restrict__ v, const int* __restrict__ step, float lr, float beta1, float beta2, float eps,
-    float tau)
+    float tau, u16* __restrict__ QB, u16* __restrict__ QTB, u16* __restrict__ QB_tgt, const int* __restrict__ idx_fb,
+    const int* __restrict__ idx_tb)
 {
     __shared__ float s_step_size, s_bc2_sqrt;
     const int tid = threadIdx.x, i = blockIdx.x * DQ_ADAM_THREADS + tid;
@@ -381,6 +384,15 @@ __global__ __launch_bounds__(DQ_ADAM_THREADS) void dqn_adam_kernel(
     const int jf = idx_f[i], jt = idx_t[i];
     if (jf >= 0) { PF[jf] = p; PF_tgt[jf] = pt; }
     if (jt >= 0) PT[jt] = p;
+    if (QB) {       // the three-term bf16 planes of the fused update (dqn_fused.inc): online forward / transposed, target forward
+        u16 a, b, c;
+        const int kf = idx_fb[i], kt = idx_tb[i];
+        split3(p, a, b, c);
+        if (kf >= 0) { QB[kf] = a; QB[kf + 512] = b; QB[kf + 1024] = c; }
+        if (kt >= 0) { QTB[kt] = a; QTB[kt + 512] = b; QTB[kt + 1024] = c; }
+        split3(pt, a, b, c);
+        if (kf >= 0) { QB_tgt[kf] = a; QB_tgt[kf + 512] = b; QB_tgt[kf + 1024] = c; }
+    }
 }
 
 __global__ void dqn_step_inc_kernel(int* step) { *step += 1; }
@@ -465,12 +477,72 @@ extern "C" hipError_t flyhip_launch_dqn_grad_w(const float* x, const float* h1, 
 extern "C" hipError_t flyhip_launch_dqn_adam(float* P, float* PF, float* PT, float* P_tgt, float* PF_tgt, const int* idx_f,
                                              const int* idx_t, const float* G, const float* mask, float* m, float* v,
                                              int* step, float lr, float beta1, float beta2, float eps, float tau,
+                                             uint16_t* QB, uint16_t* QTB, uint16_t* QB_tgt, const int* idx_fb, const int* idx_tb,
                                              void* stream)
 {
     hipLaunchKernelGGL(dqn_adam_kernel, dim3(DQ_ADAM_BLOCKS), dim3(DQ_ADAM_THREADS), 0, (hipStream_t)stream, P, PF, PT, P_tgt,
-                       PF_tgt, idx_f, idx_t, G, mask, m, v, step, lr, beta1, beta2, eps, tau);
+                       PF_tgt, idx_f, idx_t, G, mask, m, v, step, lr, beta1, beta2, eps, tau, QB, QTB, QB_tgt, idx_fb, idx_tb);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(dqn_step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
+    return hipGetLastError();
+}
+
+// ---- the fused update: dqn_chain_kernel + dqn_dw2_kernel + the fixed-order reduction of their per-workgroup slabs -----------------
+static int dqn_cus()
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
+    }
+    return cus;
+}
+
+static unsigned long long* g_dqn_stamps = nullptr;       // diagnostics (tools/stamp_dqn.py): u64 [workgroups][16], normally null
+extern "C" void flyhip_debug_set_dqn_stamps(unsigned long long* p) { g_dqn_stamps = p; }
+extern "C" int64_t flyhip_dqn_fused_workspace_floats(void) { return (int64_t)dqn_cus() * DQN_PACKED_FLOATS; }
+extern "C" int64_t flyhip_dqn_fused_image_halves(int64_t rows) { return (rows / BM) * 2 * (int64_t)DF_IMAGE_HALVES; }
+
+extern "C" hipError_t flyhip_launch_dqn_fused_update(const float* P, const uint16_t* QB, const uint16_t* QTB, const float* P_tgt,
+                                                     const uint16_t* QB_tgt, const void* chunks, int S, int64_t n, float discount,
+                                                     float inv_B, uint16_t* images, float* workspace, float* grad, float* loss_part,
+                                                     int rows_aligned16, void* stream)
+{
+    const long tiles_per = n / BM, ntiles = (long)S * tiles_per;
+    const int cus = dqn_cus();
+    const int grid = (int)(ntiles < cus ? ntiles : cus);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(dqn_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            DF_LDS_BYTES);
+        if (ea != hipSuccess) return ea;
+        ea = hipFuncSetAttribute(reinterpret_cast<const void*>(dqn_dw2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW2_LDS_BYTES);
+        if (ea != hipSuccess) return ea;
+        attr_set = true;
+    }
+    float* ws1 = workspace;
+    float* ws2 = ws1 + (long)cus * DF_STRIDE1;
+    float* ws3 = ws2 + (long)cus * DF_STRIDE2;
+    hipLaunchKernelGGL(dqn_chain_kernel, dim3(grid), dim3(THREADS), DF_LDS_BYTES, (hipStream_t)stream, P, QB, QTB, P_tgt, QB_tgt,
+                       static_cast<const DqnChunk*>(chunks), S, tiles_per, discount, inv_B, images, ws1, ws2, ws3, loss_part, g_dqn_stamps,
+                       rows_aligned16);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(dqn_dw2_kernel, dim3(grid), dim3(THREADS), DW2_LDS_BYTES, (hipStream_t)stream, images, ntiles, ws2);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    GradWTable T;
+    float* part[3] = {ws1, ws2, ws3};
+    const int N[3] = {DQN_H, DQN_H, DQN_OUT};
+    const int KP[3] = {DQN_IN_PAD, DQN_H, DQN_H};
+    for (int l = 0; l < 3; ++l) {
+        T.l[l].dz = nullptr; T.l[l].a = nullptr; T.l[l].partial = part[l];
+        T.l[l].N = N[l]; T.l[l].Ka = KP[l]; T.l[l].KP = KP[l]; T.l[l].wgs = grid; T.l[l].first_block = 0; T.l[l].accumulate = 0;
+        T.l[l].chunked = 0;
+    }
+    T.l[3] = T.l[2];
+    hipLaunchKernelGGL(dqn_grad_reduce_kernel, dim3(DQ_RED_BLOCKS), dim3(64 * DQ_RED_WAVES), 0, (hipStream_t)stream, T, grad, 0);
     return hipGetLastError();
 }

@@ -42,7 +42,7 @@ extern "C" hipError_t flyhip_launch_dqn_grad_w(const float* x, const float* h1, 
                                                int accumulate, void* stream);
 extern "C" hipError_t flyhip_launch_dqn_adam(float* P, float* PF, float* PT, float* P_tgt, float* PF_tgt, const int* idx_f,
                                              const int* idx_t, const float* G, const float* mask, float* m, float* v,
-                                             int* step, float lr, float beta1, float beta2, float eps, float tau,
+                                             int* step, float lr, float beta1, float beta2, float eps, float tau, uint16_t* QB, uint16_t* QTB, uint16_t* QB_tgt, const int* idx_fb, const int* idx_tb,
                                              void* stream);
 extern "C" hipError_t flyhip_p2p_alloc(int64_t n_floats, void** out);
 extern "C" hipError_t flyhip_launch_p2p_allreduce(float* G, int64_t n, void* const* bases, int rank, int world,
@@ -165,7 +165,7 @@ int launch(FlyHandle h, int phases, const float* actions, const FlyBuffers* b, v
 extern "C" {
 
 const char* fly_last_error(void) { return g_err; }
-int fly_abi_version(void) { return 8; }
+int fly_abi_version(void) { return 9; }
 
 int fly_create(const FlyConfig* cfg, FlyHandle* out)
 {
@@ -545,14 +545,43 @@ int dqn_grad_w(const float* x, const float* h1, const float* h2, const float* dz
 int dqn_adam_soft_update(float* params, float* params_frag, float* params_t_frag, float* target_params,
                          float* target_params_frag, const int32_t* idx_frag, const int32_t* idx_t_frag,
                          const float* grad, const float* mask, float* exp_avg, float* exp_avg_sq, int32_t* step,
-                         float lr, float beta1, float beta2, float eps, float tau, void* stream)
+                         float lr, float beta1, float beta2, float eps, float tau, uint16_t* params_b3, uint16_t* params_t_b3,
+                         uint16_t* target_params_b3, const int32_t* idx_b3, const int32_t* idx_t_b3, void* stream)
 {
     if (!params || !params_frag || !params_t_frag || !target_params || !target_params_frag || !idx_frag || !idx_t_frag ||
         !grad || !mask || !exp_avg || !exp_avg_sq || !step)
         return fail(FLY_E_ARG, "dqn_adam_soft_update: null pointer");
+    if (params_b3 && (!params_t_b3 || !target_params_b3 || !idx_b3 || !idx_t_b3))
+        return fail(FLY_E_ARG, "dqn_adam_soft_update: params_b3 needs params_t_b3, target_params_b3, idx_b3 and idx_t_b3");
     hipError_t e = flyhip_launch_dqn_adam(params, params_frag, params_t_frag, target_params, target_params_frag, idx_frag,
-                                          idx_t_frag, grad, mask, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, tau, stream);
+                                          idx_t_frag, grad, mask, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, tau,
+                                          params_b3, params_t_b3, target_params_b3, idx_b3, idx_t_b3, stream);
     if (e != hipSuccess) return hip_fail(e, "dqn_adam_soft_update launch");
+    return FLY_OK;
+}
+
+extern "C" int64_t flyhip_dqn_fused_workspace_floats(void);
+extern "C" int64_t flyhip_dqn_fused_image_halves(int64_t rows);
+extern "C" hipError_t flyhip_launch_dqn_fused_update(const float* P, const uint16_t* QB, const uint16_t* QTB, const float* P_tgt,
+                                                     const uint16_t* QB_tgt, const void* chunks, int S, int64_t n, float discount,
+                                                     float inv_B, uint16_t* images, float* workspace, float* grad, float* loss_part,
+                                                     int rows_aligned16, void* stream);
+
+int64_t dqn_fused_workspace_floats(void) { return flyhip_dqn_fused_workspace_floats(); }
+int64_t dqn_fused_image_halves(int64_t rows) { return flyhip_dqn_fused_image_halves(rows); }
+
+int dqn_fused_update(const float* params, const uint16_t* params_b3, const uint16_t* params_t_b3, const float* target_params,
+                     const uint16_t* target_params_b3, const void* chunks, int32_t num_chunks, int64_t n, float discount, float inv_B,
+                     uint16_t* images, float* workspace, float* grad, float* loss_part, int32_t rows_aligned16, void* stream)
+{
+    if (!params || !params_b3 || !params_t_b3 || !target_params || !target_params_b3 || !chunks || !images || !workspace || !grad ||
+        !loss_part)
+        return fail(FLY_E_ARG, "dqn_fused_update: null pointer");
+    if (num_chunks <= 0 || n <= 0 || (n % 32) != 0)
+        return fail(FLY_E_ARG, "dqn_fused_update: needs num_chunks > 0 and n a positive multiple of 32 (whole tiles; use dqn_td_step + dqn_grad_w otherwise)");
+    hipError_t e = flyhip_launch_dqn_fused_update(params, params_b3, params_t_b3, target_params, target_params_b3, chunks, num_chunks, n,
+                                                  discount, inv_B, images, workspace, grad, loss_part, rows_aligned16 ? 1 : 0, stream);
+    if (e != hipSuccess) return hip_fail(e, "dqn_fused_update launch");
     return FLY_OK;
 }
 

@@ -67,6 +67,34 @@ def build_index_maps():
     return idx_f, idx_t
 
 
+QB_HALVES = 3 * (H * IN_PAD + H * H + OUT * H)      # 282624 (csrc/dqn_layout.h)
+QTB_HALVES = 3 * (H * OUT + H * H)                  # 221184
+OFF_QB = (0, 3 * H * IN_PAD, 3 * (H * IN_PAD + H * H))
+OFF_QTB3, OFF_QTB2 = 0, 3 * H * OUT
+
+
+def build_plane_maps():
+    """int32 [PACKED] maps master index -> term-0 position in the bf16x3 plane buffers QB / QTB (-1: no copy); terms 1 and 2
+    follow 512 and 1024 16-bit words later (csrc/dqn_layout.h, the operand order of csrc/mlp_layout.h)."""
+    import numpy as np
+    from .policy import _plane_index
+    idx_fb = np.full(PACKED, -1, np.int32)
+    idx_tb = np.full(PACKED, -1, np.int32)
+    for li, (off_w, N, K) in enumerate(((OFF_W1, H, IN_PAD), (OFF_W2, H, H), (OFF_W3, OUT, H))):
+        n, k = np.meshgrid(np.arange(N), np.arange(K), indexing="ij")
+        src = off_w + n * K + k
+        idx_fb[src] = OFF_QB[li] + _plane_index(n, k, K)
+        if li == 1:
+            idx_tb[src] = OFF_QTB2 + _plane_index(k, n, N)          # W2^T: 256 outputs, 256 reduced
+        elif li == 2:
+            idx_tb[src] = OFF_QTB3 + _plane_index(k, n, N)          # W3^T: 256 outputs, 32 reduced
+    for idx, size in ((idx_fb, QB_HALVES), (idx_tb, QTB_HALVES)):
+        used = idx[idx >= 0].astype(np.int64)
+        allpos = np.concatenate([used, used + 512, used + 1024])
+        assert len(np.unique(allpos)) == len(allpos) == size and allpos.max() == size - 1
+    return idx_fb, idx_tb
+
+
 class Net(nn.Module):
     """dqn.py:17-29."""
 
@@ -174,14 +202,31 @@ class QNetPacked:
         assert int(mask.sum()) == IN * H + H + H * H + H + NACT * H + NACT
         self.G, self.exp_avg, self.exp_avg_sq = z(PACKED), z(PACKED), z(PACKED)
         self.step = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # three-term bf16 planes of the fused update (csrc/dqn_fused.inc): online forward / transposed, target forward
+        zi = lambda k: torch.zeros(k, dtype=torch.int16, device=self.device)   # noqa: E731
+        self.QB, self.QTB, self.QB_tgt = zi(QB_HALVES), zi(QTB_HALVES), zi(QB_HALVES)
+        idx_fb, idx_tb = build_plane_maps()
+        self.idx_fb = torch.from_numpy(idx_fb).to(self.device)
+        self.idx_tb = torch.from_numpy(idx_tb).to(self.device)
+        self._src_fb = torch.nonzero(self.idx_fb >= 0).squeeze(-1); self._dst_fb = self.idx_fb[self._src_fb].long()
+        self._src_tb = torch.nonzero(self.idx_tb >= 0).squeeze(-1); self._dst_tb = self.idx_tb[self._src_tb].long()
         self.refresh()
 
     def refresh(self):
-        """Rebuild the fragment copies from the packed masters (after a load / out-of-band change)."""
+        """Rebuild the fragment copies and term planes from the packed masters (after a load / out-of-band change)."""
+        from .policy import split_bf16x3
         with torch.no_grad():
             self.PF[self._dst_f] = self.P[self._src_f]
             self.PT[self._dst_t] = self.P[self._src_t]
             self.PF_tgt[self._dst_f] = self.P_tgt[self._src_f]
+            for dst_buf, master, src, dst in ((self.QB, self.P, self._src_fb, self._dst_fb), (self.QTB, self.P, self._src_tb, self._dst_tb),
+                                              (self.QB_tgt, self.P_tgt, self._src_fb, self._dst_fb)):
+                for term, plane in enumerate(split_bf16x3(master[src])):
+                    dst_buf[dst + 512 * term] = plane
+
+    def plane_args(self):
+        p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+        return (p(self.QB), p(self.QTB), p(self.QB_tgt), p(self.idx_fb), p(self.idx_tb))
 
 
 class DQN:
@@ -213,6 +258,11 @@ class DQN:
         self._lib = _lib.load()
         self.packed = QNetPacked(self.q, self.q_target, dev)
         self._alloc_workspace(n)
+        # the update's gradient through the fused bf16x3 launches (csrc/dqn_fused.inc) whenever the row blocks are whole 32-row tiles
+        # of one size; FLY_DQN_FUSED=0 / args.dqn_fused=False keeps the per-step fp32-MFMA launches (the A/B)
+        import os
+        want = getattr(args, "dqn_fused", None)
+        self.fused_update = (os.environ.get("FLY_DQN_FUSED", "1") != "0") if want is None else bool(want)
         self._gen = torch.Generator(device=dev)
         self._gen.manual_seed(int(getattr(args, "seed", 0)))
         self._coin = torch.empty(n, device=dev)
@@ -231,6 +281,40 @@ class DQN:
         # per-tile Huber sums of every sampled step of one update (summed ONCE at its end, not per step)
         self._loss_part = torch.zeros(max(1, int(getattr(self, "mini_batch_size", 1))), r // 32, device=dev)
 
+    def _update_fused(self, chunks, inv_B):
+        """The gradient of one update through `dqn_fused_update` (csrc/dqn_fused.inc): ALL sampled steps in two persistent launches
+        (chain per tile with dW1 / dW3 in registers; dW2 over the saved H1 / dZ2 plane images) + one slab reduction.  bf16x3."""
+        pk, lib = self.packed, self._lib
+        p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+        S, n = len(chunks), int(chunks[0][0].shape[0])
+        tiles = S * n // 32
+        if getattr(self, "_fu_rows", 0) < S * n:
+            self._fu_rows = S * n
+            self._fu_images = torch.empty(int(lib.dqn_fused_image_halves(C.c_int64(S * n))), dtype=torch.int16, device=self.device)
+            self._fu_ws = torch.empty(int(lib.dqn_fused_workspace_floats()), device=self.device)
+            self._fu_loss = torch.zeros(tiles, device=self.device)
+            self._fu_tab = [(torch.empty((S, 5), dtype=torch.int64, pin_memory=True), torch.empty((S, 5), dtype=torch.int64, device=self.device),
+                             [None]) for _ in range(4)]
+            self._fu_i = 0
+        host, dev, ev = self._fu_tab[self._fu_i % len(self._fu_tab)]
+        self._fu_i += 1
+        if ev[0] is not None:
+            ev[0].synchronize()                               # the copy that last used this pinned buffer (4 updates ago) is long done
+        aligned = 1
+        for i, (obs, act, reward, next_obs, done_mask) in enumerate(chunks):
+            host[i, 0], host[i, 1], host[i, 2] = obs.data_ptr(), next_obs.data_ptr(), act.data_ptr()
+            host[i, 3], host[i, 4] = reward.data_ptr(), done_mask.data_ptr()
+            if (obs.data_ptr() | next_obs.data_ptr()) & 15:
+                aligned = 0
+        dev[:S].copy_(host[:S], non_blocking=True)
+        ev[0] = torch.cuda.Event()
+        ev[0].record()
+        loss_part = self._fu_loss[:tiles]
+        _lib.check(lib.dqn_fused_update(p(pk.P), p(pk.QB), p(pk.QTB), p(pk.P_tgt), p(pk.QB_tgt), p(dev), C.c_int(S), C.c_int64(n),
+                                        C.c_float(self.discount), C.c_float(inv_B), p(self._fu_images), p(self._fu_ws), p(pk.G),
+                                        p(loss_part), C.c_int(aligned), _lib.stream_ptr()), "dqn_fused_update")
+        return loss_part
+
     def update(self, chunks=None):
         """dqn.py:64-85.  `chunks` (tests) = a list of `(obs, act, reward, next_obs, done_mask)` row blocks that
         together form the batch; default: `mini_batch_size` sampled steps of the replay ring."""
@@ -241,6 +325,17 @@ class DQN:
         st = _lib.stream_ptr()
         B = sum(int(c[0].shape[0]) for c in chunks)
         inv_B = 1.0 / float(B)
+        n0 = int(chunks[0][0].shape[0])
+        if self.fused_update and n0 % 32 == 0 and all(int(c[0].shape[0]) == n0 for c in chunks):
+            for c in chunks:
+                for t in c:
+                    assert t.is_contiguous() and t.dtype == torch.float32
+            loss_part = self._update_fused(chunks, inv_B)
+            _lib.check(lib.dqn_adam_soft_update(p(pk.P), p(pk.PF), p(pk.PT), p(pk.P_tgt), p(pk.PF_tgt), p(pk.idx_f), p(pk.idx_t),
+                                                p(pk.G), p(pk.grad_mask), p(pk.exp_avg), p(pk.exp_avg_sq), p(pk.step),
+                                                C.c_float(self.lr), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8),
+                                                C.c_float(self.tau), *pk.plane_args(), st), "dqn_adam_soft_update")
+            return loss_part.sum() * inv_B
         if len(chunks) > self._loss_part.shape[0] or max(int(c[0].shape[0]) for c in chunks) > self._ws_rows:
             self.mini_batch_size = max(self.mini_batch_size, len(chunks))
             self._alloc_workspace(max(int(c[0].shape[0]) for c in chunks))
@@ -259,7 +354,7 @@ class DQN:
         _lib.check(lib.dqn_adam_soft_update(p(pk.P), p(pk.PF), p(pk.PT), p(pk.P_tgt), p(pk.PF_tgt), p(pk.idx_f), p(pk.idx_t),
                                             p(pk.G), p(pk.grad_mask), p(pk.exp_avg), p(pk.exp_avg_sq), p(pk.step),
                                             C.c_float(self.lr), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8),
-                                            C.c_float(self.tau), st), "dqn_adam_soft_update")
+                                            C.c_float(self.tau), *pk.plane_args(), st), "dqn_adam_soft_update")
         return self._loss_part.sum() * inv_B                              # F.smooth_l1_loss: mean over the batch
 
     def q_parameters(self):

@@ -413,7 +413,13 @@ int dqn_huber_td(const float* q_table, const float* act, const float* reward, co
  *                   of its fragment copies, then target = target * tau + params * (1 - tau)
  *                   (dqn.py:33-36) with the target's forward fragment copy.  `mask` (packed, 0/1) freezes
  *                   padding; `step` device int counter; idx_* int32 [DQN_PACKED_FLOATS_ABI] (-1: no copy).
+ *                   params_b3 != NULL (all five or none): also keeps the three-term bf16 planes the fused update
+ *                   streams -- online forward (DQN_QB_HALVES_ABI 16-bit words) and transposed (DQN_QTB_HALVES_ABI),
+ *                   target forward -- term 0 at idx_b3[i] / idx_t_b3[i], terms 1 and 2 512 and 1024 words later
+ *                   (layout: csrc/dqn_layout.h).
  */
+#define DQN_QB_HALVES_ABI 282624
+#define DQN_QTB_HALVES_ABI 221184
 #define DQN_PACKED_FLOATS_ABI 94752
 #define DQN_FRAG_FLOATS_ABI 94208
 #define DQN_FRAG_T_FLOATS_ABI 73728
@@ -428,10 +434,28 @@ int dqn_td_step(const float* params, const float* params_frag, const float* para
 int64_t dqn_grad_workspace_floats(void);
 int dqn_grad_w(const float* x, const float* h1, const float* h2, const float* dz1, const float* dz2,
                const float* dz3, int64_t n, float* workspace, float* grad, int32_t accumulate, void* stream);
+/* The whole gradient of ONE update (dqn.py:64-80) over all its sampled replay steps in two persistent launches + one reduction,
+ * bf16x3 arithmetic (params_b3 / params_t_b3 / target_params_b3: the planes dqn_adam_soft_update maintains): `chunks` is a DEVICE
+ * array of num_chunks records {obs, next_obs, act, reward, done} (five device pointers: rows of the replay ring where they lie, n rows
+ * each, n a multiple of 32).  A 32-row tile's target forward, online forward, TD target, Huber loss, dX chain and dW1 / dW3 run in the
+ * workgroup that owns the tile, with dW accumulated in registers across ALL tiles of the update; only the two plane images the
+ * 256 x 256 layer's dW needs (H1, dZ2: 96 KB per tile) go to `images` (dqn_fused_image_halves(num_chunks * n) 16-bit words), which
+ * the second launch streams back once.  `workspace`: dqn_fused_workspace_floats() floats of partial slabs; `grad`: the packed
+ * gradient (dqn_adam_soft_update's input); loss_part f32 [num_chunks * n / 32]: per-tile sums of the Huber terms.
+ * rows_aligned16 != 0: the caller vouches that every obs / next_obs pointer of `chunks` is 16-byte aligned (the table lives on the
+ * device, the library cannot look): the rows then travel by LDS-DMA, requested a pass ahead; 0: plain loads where they are needed. */
+int64_t dqn_fused_workspace_floats(void);
+int64_t dqn_fused_image_halves(int64_t rows);
+int dqn_fused_update(const float* params, const uint16_t* params_b3, const uint16_t* params_t_b3, const float* target_params,
+                     const uint16_t* target_params_b3, const void* chunks, int32_t num_chunks, int64_t n, float discount,
+                     float inv_B, uint16_t* images, float* workspace, float* grad, float* loss_part,
+                     int32_t rows_aligned16, void* stream);
 int dqn_adam_soft_update(float* params, float* params_frag, float* params_t_frag, float* target_params,
                          float* target_params_frag, const int32_t* idx_frag, const int32_t* idx_t_frag,
                          const float* grad, const float* mask, float* exp_avg, float* exp_avg_sq, int32_t* step,
-                         float lr, float beta1, float beta2, float eps, float tau, void* stream);
+                         float lr, float beta1, float beta2, float eps, float tau, uint16_t* params_b3,
+                         uint16_t* params_t_b3, uint16_t* target_params_b3, const int32_t* idx_b3,
+                         const int32_t* idx_t_b3, void* stream);
 
 
 /*

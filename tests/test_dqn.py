@@ -63,7 +63,7 @@ def test_hip_huber_td_vs_reference_and_oracle(golden):
     np.testing.assert_allclose(dq.cpu().numpy(), dq2, rtol=3e-7, atol=0)     # d/B vs d*(1/B): one ulp
 
 
-def _bare_dqn(golden_sd=None, rows=384):
+def _bare_dqn(golden_sd=None, rows=384, fused=False):
     """A DQN without an environment: the packed Q-network pair + workspace on cuda:0."""
     from fly_bproject_amd import _lib
     from fly_bproject_amd.dqn import DQN, Net, QNetPacked, soft_update
@@ -77,6 +77,7 @@ def _bare_dqn(golden_sd=None, rows=384):
     d._lib = _lib.load()
     d.packed = QNetPacked(d.q, d.q_target, "cuda:0")
     d._alloc_workspace(rows)
+    d.fused_update = fused
     return d
 
 
@@ -130,7 +131,8 @@ def test_fused_act_equals_forward_plus_eps_greedy(golden, eps):
 
 
 @pytest.mark.gpu
-def test_dqn_update_matches_reference_step(golden):
+@pytest.mark.parametrize("fused", [False, True])
+def test_dqn_update_matches_reference_step(golden, fused):
     """One DQN.update from the reference's weights on the reference's batch, all on the HIP kernels
     (dqn_td_step + dqn_grad_w + dqn_adam_soft_update): same loss, same Q-network and target network
     afterwards (Adam 3e-4 + soft update 0.995) -- as ONE chunk and as four chunks whose gradients accumulate."""
@@ -138,8 +140,9 @@ def test_dqn_update_matches_reference_step(golden):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")   # noqa: E731
     batch = (t(g["b_obs"]), t(g["b_act"]), t(g["b_rew"]), t(g["b_next"]), t(g["b_done"]))
     B = batch[0].shape[0]
+    assert B % 128 == 0                      # whole 32-row tiles in four chunks too: the fused launches take both splits
     for parts in (1, 4):
-        d = _bare_dqn({k[2:]: t(g[k]) for k in g.files if k.startswith("q_") and "." in k})
+        d = _bare_dqn({k[2:]: t(g[k]) for k in g.files if k.startswith("q_") and "." in k}, fused=fused)
         step = B // parts
         chunks = [tuple(x[i * step:(i + 1) * step].contiguous() for x in batch) for i in range(parts)]
         loss = d.update(chunks)
@@ -153,21 +156,24 @@ def test_dqn_update_matches_reference_step(golden):
         # padding never moves, fragment copies follow the masters
         assert torch.all(d.packed.P[:256 * 80].view(256, 80)[:, 73:] == 0)
         pf, pt, pft = d.packed.PF.clone(), d.packed.PT.clone(), d.packed.PF_tgt.clone()
+        qb, qtb, qbt = d.packed.QB.clone(), d.packed.QTB.clone(), d.packed.QB_tgt.clone()
         d.packed.refresh()
         assert torch.equal(pf, d.packed.PF) and torch.equal(pt, d.packed.PT) and torch.equal(pft, d.packed.PF_tgt)
+        assert torch.equal(qb, d.packed.QB) and torch.equal(qtb, d.packed.QTB) and torch.equal(qbt, d.packed.QB_tgt)   # the bf16x3 planes too
 
 
 @pytest.mark.gpu
-def test_dqn_td_gradient_matches_autograd():
+@pytest.mark.parametrize("fused,B", [(False, 1000), (True, 1024), (True, 16384)])
+def test_dqn_td_gradient_matches_autograd(fused, B):
     """The packed gradient of one update batch (TD target from the target net, Huber, backward, dW) against
-    torch autograd on the same module in fp64-free fp32; random weights, 1000 rows (ragged tile)."""
+    torch autograd on the same module in fp64-free fp32; random weights; 1000 rows (ragged tile) through the per-step
+    launches, whole tiles through the fused bf16x3 launches (16384 rows: every workgroup walks two tiles)."""
     torch.manual_seed(5)
-    d = _bare_dqn(rows=1000)
+    d = _bare_dqn(rows=B, fused=fused)
     with torch.no_grad():
         for p_ in d.q_target.parameters():
             p_.add_(0.05 * torch.randn_like(p_))                 # target differs from online
     d.packed.refresh()
-    B = 1000
     obs = torch.randn(B, 73, device="cuda:0"); nxt = torch.randn(B, 73, device="cuda:0")
     act = torch.rand(B, device="cuda:0") * 2 - 1
     rew = torch.randn(B, device="cuda:0") * 2; done = (torch.rand(B, device="cuda:0") > 0.1).float()

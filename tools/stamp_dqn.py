@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Per-phase shader cycles of dqn_chain_kernel (the second tile of every workgroup, thread 0) and HIP-event times of one fused DQN
+update at 32768 envs x S sampled steps: stamp_dqn.py [S]"""
+import contextlib
+import ctypes as C
+import io
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from bench import make_args  # noqa: E402
+from fly_bproject_amd import _lib  # noqa: E402
+from fly_bproject_amd.dqn import DQN  # noqa: E402
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+n = 32768
+with contextlib.redirect_stdout(io.StringIO()):
+    agent = DQN(make_args(n, dqn_mini_batch_size=S, replay_steps=max(2 * S, 8)))
+    for _ in range(S + 2):
+        agent.run()
+torch.cuda.synchronize()
+lib = _lib.load()
+stamps = torch.zeros(256 * 16, dtype=torch.int64, device="cuda:0")
+lib.flyhip_debug_set_dqn_stamps.argtypes = [C.c_void_p]
+lib.flyhip_debug_set_dqn_stamps.restype = None
+for rep in range(3):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    lib.flyhip_debug_set_dqn_stamps(C.c_void_p(stamps.data_ptr()) if rep == 2 else None)
+    e0.record()
+    agent.update()
+    e1.record()
+    torch.cuda.synchronize()
+    print("update of %d sampled steps x %d rows: %.2f ms (%.1f us per sampled step)" % (S, n, e0.elapsed_time(e1), e0.elapsed_time(e1) * 1e3 / S))
+lib.flyhip_debug_set_dqn_stamps(None)
+s = stamps.cpu().numpy().reshape(256, 16)
+names = ["target: rows in + x planes", "target L1", "target L2", "target L3 + partials", "target max, barrier", "online: rows in + x planes",
+         "online L1", "online L2", "online L3 + partials", "loss + dZ3", "dA2, dZ2, dW3, db", "dA1, dZ1, dW1", "image copy-out", ]
+d = np.diff(s[:, :14], axis=1).astype(np.float64)
+ok = (s[:, 13] > 0)
+print("workgroups stamped: %d; cycles per tile %.0f" % (ok.sum(), d[ok].sum(1).mean()))
+for i, nm in enumerate(names):
+    print("  %-30s %8.0f" % (nm, d[ok][:, i].mean()))
+agent.exit()
