@@ -511,6 +511,7 @@ extern "C" hipError_t flyhip_launch_dqn_fused_update(const float* P, const uint1
                                                      int rows_aligned16, void* stream)
 {
     const long tiles_per = n / BM, ntiles = (long)S * tiles_per;
+    if (ntiles <= 0 || ntiles + 4096 >= (1L << 31)) return hipErrorInvalidValue;          // the kernels count tiles in 32 bits
     const int cus = dqn_cus();
     const int grid = (int)(ntiles < cus ? ntiles : cus);
     static bool attr_set = false;

@@ -23,7 +23,7 @@ with contextlib.redirect_stdout(io.StringIO()):
         agent.run()
 torch.cuda.synchronize()
 lib = _lib.load()
-stamps = torch.zeros(256 * 16, dtype=torch.int64, device="cuda:0")
+stamps = torch.zeros(256 * 64, dtype=torch.int64, device="cuda:0")
 lib.flyhip_debug_set_dqn_stamps.argtypes = [C.c_void_p]
 lib.flyhip_debug_set_dqn_stamps.restype = None
 for rep in range(3):
@@ -35,7 +35,7 @@ for rep in range(3):
     torch.cuda.synchronize()
     print("update of %d sampled steps x %d rows: %.2f ms (%.1f us per sampled step)" % (S, n, e0.elapsed_time(e1), e0.elapsed_time(e1) * 1e3 / S))
 lib.flyhip_debug_set_dqn_stamps(None)
-s = stamps.cpu().numpy().reshape(256, 16)
+s = stamps.cpu().numpy().reshape(256, 64)
 names = ["target: rows in + x planes", "target L1", "target L2", "target L3 + partials", "target max, barrier", "online: rows in + x planes",
          "online L1", "online L2", "online L3 + partials", "loss + dZ3", "dA2, dZ2, dW3, db", "dA1, dZ1, dW1", "image copy-out", ]
 d = np.diff(s[:, :14], axis=1).astype(np.float64)
@@ -43,4 +43,13 @@ ok = (s[:, 13] > 0)
 print("workgroups stamped: %d; cycles per tile %.0f" % (ok.sum(), d[ok].sum(1).mean()))
 for i, nm in enumerate(names):
     print("  %-30s %8.0f" % (nm, d[ok][:, i].mean()))
+fine = ["L1 GEMM a", "L1 GEMM b (+ epilogue a)", "L1 epilogue b", "barrier", "L2 GEMM a", "L2 GEMM b (+ epilogue a)", "L2 epilogue b", "barrier",
+        "L3 GEMM", "partials + barrier"]
+for ps, (base, c0) in enumerate(((16, 1), (32, 6))):
+    t = s[ok].astype(np.float64)
+    seq = [t[:, c0], t[:, base + 0], t[:, base + 1], t[:, base + 2], t[:, c0 + 1], t[:, base + 3], t[:, base + 4], t[:, base + 5],
+           t[:, c0 + 2], t[:, base + 6], t[:, c0 + 3]]
+    print("  inside the %s pass (wave 0):" % ("target", "online")[ps])
+    for i, nm in enumerate(fine):
+        print("    %-28s %8.0f" % (nm, (seq[i + 1] - seq[i]).mean()))
 agent.exit()
