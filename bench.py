@@ -657,25 +657,50 @@ def dqn_measure(n, mb, warmup, steps, kernel_reps):
     p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
     pk, rp = agent.packed, agent.replay
     st = _lib.stream_ptr()
-    t_td = _time_launches(lambda: lib.dqn_td_step(p(pk.P), p(pk.PF), p(pk.PT), p(pk.P_tgt), p(pk.PF_tgt), p(rp.obs[0]),
-                                                  p(rp.next_obs[0]), p(rp.action[0]), p(rp.reward[0]), p(rp.done[0]), n,
-                                                  C.c_float(0.99), C.c_float(1.0 / (n * mb)), p(agent._h1), p(agent._h2),
-                                                  p(agent._dz3), p(agent._dz2), p(agent._dz1), p(agent._loss_part[0]), st),
-                          kernel_reps)
-    t_gw = _time_launches(lambda: lib.dqn_grad_w(p(rp.obs[0]), p(agent._h1), p(agent._h2), p(agent._dz1), p(agent._dz2),
-                                                 p(agent._dz3), n, p(agent._gw_ws), p(pk.G), 1, st), kernel_reps)      # a middle step of a batch: no reduction
     t_act = _time_launches(lambda: lib.dqn_act(p(pk.P), p(pk.PF), p(rp.obs[0]), n, p(agent._coin), p(agent._rand),
                                                C.c_float(0.1), p(agent._dz3), None, st), kernel_reps)
 
-    def mfma(name, dur, flop, per_step):
+    def mfma(name, dur, flop, per_step, peak=PEAK_F32_MFMA_TFLOPS):
         ach = flop / dur / 1e12
-        return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 5), "traffic": None, "avg_launch_us": round(dur * 1e6, 3),
+        return {"kernel": name, "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 5), "traffic": None, "avg_launch_us": round(dur * 1e6, 3),
                 "algorithmic_per_launch": flop, "launches_per_step": per_step, "step_share_ms": round(dur * per_step * 1e3, 3)}
-    ks = [mfma("dqn_td_kernel (target fwd + online fwd + Huber-TD + dX chain, %d rows)" % n, t_td,
-               (2 * DQN_FWD_FLOP + DQN_BWD_DX_FLOP) * n, mb),
-          mfma("dqn_grad_w_kernel (partials accumulate; one reduction per update)", t_gw, DQN_FWD_FLOP * n, mb),
-          mfma("dqn_act_kernel (forward + argmax + eps-greedy)", t_act, DQN_FWD_FLOP * n, 1)]
+    fused = bool(agent.fused_update) and n % 32 == 0
+    if fused:
+        # the update as it runs: dqn_fused_update = dqn_chain_kernel + dqn_dw2_kernel + the slab reduction, once per update over all
+        # `mb` sampled steps.  Each launch timed alone (flyhip_debug_set_dqn_fused_phases), on the update's own sampled chunks.
+        lib.flyhip_debug_set_dqn_fused_phases.argtypes = [C.c_int]
+        lib.flyhip_debug_set_dqn_fused_phases.restype = None
+        chunks = rp.sample(mb)
+        inv_B = 1.0 / float(n * mb)
+        t = {}
+        for name, mask in (("chain", 1), ("dw2", 2), ("reduce", 4)):
+            lib.flyhip_debug_set_dqn_fused_phases(mask)
+            t[name] = _time_launches(lambda: agent._update_fused(chunks, inv_B), 3)
+        lib.flyhip_debug_set_dqn_fused_phases(7)
+        peak = mlp_peak_for("bf16x3")
+        rows = n * mb
+        dw13 = 2 * (73 * 256 + 256 * 18)                                   # dW1 + dW3 per row
+        ks = [mfma("dqn_chain_kernel (per 32-row tile: target fwd, online fwd, Huber-TD, dX chain, dW1 / dW3 / db in registers; "
+                   "%d rows = one update)" % rows, t["chain"], (2 * DQN_FWD_FLOP + DQN_BWD_DX_FLOP + dw13) * rows, 1, peak),
+              mfma("dqn_dw2_kernel (dW2 over the saved H1 | dZ2 plane images)", t["dw2"], 2 * 256 * 256 * rows, 1, peak),
+              {"kernel": "dqn_grad_reduce_kernel (fixed-order sum of the per-CU slabs)", "avg_launch_us": round(t["reduce"] * 1e6, 3),
+               "launches_per_step": 1, "step_share_ms": round(t["reduce"] * 1e3, 3)},
+              mfma("dqn_act_kernel (forward + argmax + eps-greedy)", t_act, DQN_FWD_FLOP * n, 1)]
+        dtype = "bf16x3"
+    else:
+        t_td = _time_launches(lambda: lib.dqn_td_step(p(pk.P), p(pk.PF), p(pk.PT), p(pk.P_tgt), p(pk.PF_tgt), p(rp.obs[0]),
+                                                      p(rp.next_obs[0]), p(rp.action[0]), p(rp.reward[0]), p(rp.done[0]), n,
+                                                      C.c_float(0.99), C.c_float(1.0 / (n * mb)), p(agent._h1), p(agent._h2),
+                                                      p(agent._dz3), p(agent._dz2), p(agent._dz1), p(agent._loss_part[0]), st),
+                              kernel_reps)
+        t_gw = _time_launches(lambda: lib.dqn_grad_w(p(rp.obs[0]), p(agent._h1), p(agent._h2), p(agent._dz1), p(agent._dz2),
+                                                     p(agent._dz3), n, p(agent._gw_ws), p(pk.G), 1, st), kernel_reps)  # a middle step of a batch: no reduction
+        ks = [mfma("dqn_td_kernel (target fwd + online fwd + Huber-TD + dX chain, %d rows)" % n, t_td,
+                   (2 * DQN_FWD_FLOP + DQN_BWD_DX_FLOP) * n, mb),
+              mfma("dqn_grad_w_kernel (partials accumulate; one reduction per update)", t_gw, DQN_FWD_FLOP * n, mb),
+              mfma("dqn_act_kernel (forward + argmax + eps-greedy)", t_act, DQN_FWD_FLOP * n, 1)]
+        dtype = "f32"
     capacity, rbytes = rp.capacity, rp.bytes
     agent.exit()
     del agent
@@ -683,7 +708,8 @@ def dqn_measure(n, mb, warmup, steps, kernel_reps):
     return {
         "metric": "env-steps/sec (DQN act + env step + update), %d envs" % n, "value": round(n * steps / elapsed, 1),
         "unit": "env-steps/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "update_path": "dqn_fused_update (bf16x3 chain + dW2 over plane images)" if fused else "dqn_td_step + dqn_grad_w per sampled step (fp32 MFMA)",
         "config": {"workload": "fly_dqn_%denvs_batch%dsteps" % (n, mb), "num_envs_per_gpu": n, "sampled_steps_per_update": mb,
                    "rows_per_update": n * mb, "replay_capacity_steps": capacity, "replay_bytes": rbytes,
                    "updates_per_env_step": 1, "parallelism": "dp1"},

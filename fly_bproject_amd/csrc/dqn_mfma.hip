@@ -500,8 +500,11 @@ static int dqn_cus()
     return cus;
 }
 
-static unsigned long long* g_dqn_stamps = nullptr;       // diagnostics (tools/stamp_dqn.py): u64 [workgroups][16], normally null
+static unsigned long long* g_dqn_stamps = nullptr;       // diagnostics (tools/stamp_dqn.py): u64 [workgroups][64], normally null
 extern "C" void flyhip_debug_set_dqn_stamps(unsigned long long* p) { g_dqn_stamps = p; }
+// measurement only (bench.py times the launches one by one): bit 0 chain kernel, bit 1 dW2 kernel, bit 2 slab reduction; 7 = the update
+static int g_dqn_phases = 7;
+extern "C" void flyhip_debug_set_dqn_fused_phases(int mask) { g_dqn_phases = mask & 7; }
 extern "C" int64_t flyhip_dqn_fused_workspace_floats(void) { return (int64_t)dqn_cus() * DQN_PACKED_FLOATS; }
 extern "C" int64_t flyhip_dqn_fused_image_halves(int64_t rows) { return (rows / BM) * 2 * (int64_t)DF_IMAGE_HALVES; }
 
@@ -526,14 +529,20 @@ extern "C" hipError_t flyhip_launch_dqn_fused_update(const float* P, const uint1
     float* ws1 = workspace;
     float* ws2 = ws1 + (long)cus * DF_STRIDE1;
     float* ws3 = ws2 + (long)cus * DF_STRIDE2;
-    hipLaunchKernelGGL(dqn_chain_kernel, dim3(grid), dim3(THREADS), DF_LDS_BYTES, (hipStream_t)stream, P, QB, QTB, P_tgt, QB_tgt,
-                       static_cast<const DqnChunk*>(chunks), S, tiles_per, discount, inv_B, images, ws1, ws2, ws3, loss_part, g_dqn_stamps,
-                       rows_aligned16);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dqn_dw2_kernel, dim3(grid), dim3(THREADS), DW2_LDS_BYTES, (hipStream_t)stream, images, ntiles, ws2);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
+    if (g_dqn_phases & 1) {
+        hipLaunchKernelGGL(dqn_chain_kernel, dim3(grid), dim3(THREADS), DF_LDS_BYTES, (hipStream_t)stream, P, QB, QTB, P_tgt, QB_tgt,
+                           static_cast<const DqnChunk*>(chunks), S, tiles_per, discount, inv_B, images, ws1, ws2, ws3, loss_part,
+                           g_dqn_stamps, rows_aligned16);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (g_dqn_phases & 2) {
+        hipLaunchKernelGGL(dqn_dw2_kernel, dim3(grid), dim3(THREADS), DW2_LDS_BYTES, (hipStream_t)stream, images, ntiles, ws2);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (!(g_dqn_phases & 4)) return hipSuccess;
     GradWTable T;
     float* part[3] = {ws1, ws2, ws3};
     const int N[3] = {DQN_H, DQN_H, DQN_OUT};

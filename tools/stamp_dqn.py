@@ -52,4 +52,10 @@ for ps, (base, c0) in enumerate(((16, 1), (32, 6))):
     print("  inside the %s pass (wave 0):" % ("target", "online")[ps])
     for i, nm in enumerate(fine):
         print("    %-28s %8.0f" % (nm, (seq[i + 1] - seq[i]).mean()))
+t = s[ok].astype(np.float64)
+seq = [t[:, 11], t[:, 48], t[:, 49], t[:, 50], t[:, 51], t[:, 12]]
+print("  inside dA1 / dZ1 / dW1 (wave 0):")
+for i, nm in enumerate(["GEMM a", "GEMM b (+ dZ1 epilogue a)", "dZ2 image out", "dW1 a (+ dZ1 epilogue b)", "dW1 b"]):
+    print("    %-28s %8.0f" % (nm, (seq[i + 1] - seq[i]).mean()))
+print("  H1 image out (start of the dA2 phase) %8.0f" % (t[:, 52] - t[:, 10]).mean())
 agent.exit()
