@@ -674,9 +674,11 @@ def dqn_measure(n, mb, warmup, steps, kernel_reps):
         chunks = rp.sample(mb)
         inv_B = 1.0 / float(n * mb)
         t = {}
+        agent._update_fused(chunks, inv_B)                                   # sizes the buffers
+        dev, aligned = agent._fused_table(chunks)
         for name, mask in (("chain", 1), ("dw2", 2), ("reduce", 4)):
             lib.flyhip_debug_set_dqn_fused_phases(mask)
-            t[name] = _time_launches(lambda: agent._update_fused(chunks, inv_B), 3)
+            t[name] = _time_launches(lambda: agent._fused_launch(dev, mb, n, aligned, inv_B), 3 if mask < 4 else 20)
         lib.flyhip_debug_set_dqn_fused_phases(7)
         peak = mlp_peak_for("bf16x3")
         rows = n * mb
@@ -688,6 +690,19 @@ def dqn_measure(n, mb, warmup, steps, kernel_reps):
                "launches_per_step": 1, "step_share_ms": round(t["reduce"] * 1e3, 3)},
               mfma("dqn_act_kernel (forward + argmax + eps-greedy)", t_act, DQN_FWD_FLOP * n, 1)]
         dtype = "bf16x3"
+        # HBM bytes from the committed PMC passes (profiles/*_traffic.json: per launch of PROF_DQN_MB sampled steps -> scaled to `mb`)
+        try:
+            import glob
+            files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_traffic.json")))
+            tr = json.load(open(files[-1])) if files else {}
+            for k, nm in ((ks[0], "dqn_chain_kernel"), (ks[1], "dqn_dw2_kernel")):
+                t = next((v for kk, v in sorted(tr.items()) if kk.startswith(nm + "@") and "hbm_bytes_per_sampled_step" in v), None)
+                if t and n == 32768:
+                    k["traffic"] = t["hbm_bytes_per_sampled_step"] * mb
+                    k["traffic_per_sampled_step"] = t["hbm_bytes_per_sampled_step"]
+                    k["traffic_source"] = os.path.basename(files[-1])
+        except Exception:
+            pass
     else:
         t_td = _time_launches(lambda: lib.dqn_td_step(p(pk.P), p(pk.PF), p(pk.PT), p(pk.P_tgt), p(pk.PF_tgt), p(rp.obs[0]),
                                                       p(rp.next_obs[0]), p(rp.action[0]), p(rp.reward[0]), p(rp.done[0]), n,

@@ -296,20 +296,32 @@ class DQN:
             self._fu_tab = [(torch.empty((S, 5), dtype=torch.int64, pin_memory=True), torch.empty((S, 5), dtype=torch.int64, device=self.device),
                              [None]) for _ in range(4)]
             self._fu_i = 0
+        dev, aligned = self._fused_table(chunks)
+        return self._fused_launch(dev, S, n, aligned, inv_B)
+
+    def _fused_table(self, chunks):
+        """The device table of chunk pointers `dqn_fused_update` walks (DqnChunk[S]), through a rotating pinned staging buffer."""
+        S = len(chunks)
         host, dev, ev = self._fu_tab[self._fu_i % len(self._fu_tab)]
         self._fu_i += 1
         if ev[0] is not None:
             ev[0].synchronize()                               # the copy that last used this pinned buffer (4 updates ago) is long done
         aligned = 1
+        hn = host.numpy()                                     # (a view of the pinned block: row writes without tensor indexing)
         for i, (obs, act, reward, next_obs, done_mask) in enumerate(chunks):
-            host[i, 0], host[i, 1], host[i, 2] = obs.data_ptr(), next_obs.data_ptr(), act.data_ptr()
-            host[i, 3], host[i, 4] = reward.data_ptr(), done_mask.data_ptr()
-            if (obs.data_ptr() | next_obs.data_ptr()) & 15:
+            po, pn = obs.data_ptr(), next_obs.data_ptr()
+            hn[i] = (po, pn, act.data_ptr(), reward.data_ptr(), done_mask.data_ptr())
+            if (po | pn) & 15:
                 aligned = 0
         dev[:S].copy_(host[:S], non_blocking=True)
         ev[0] = torch.cuda.Event()
         ev[0].record()
-        loss_part = self._fu_loss[:tiles]
+        return dev, aligned
+
+    def _fused_launch(self, dev, S, n, aligned, inv_B):
+        pk, lib = self.packed, self._lib
+        p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+        loss_part = self._fu_loss[:S * n // 32]
         _lib.check(lib.dqn_fused_update(p(pk.P), p(pk.QB), p(pk.QTB), p(pk.P_tgt), p(pk.QB_tgt), p(dev), C.c_int(S), C.c_int64(n),
                                         C.c_float(self.discount), C.c_float(inv_B), p(self._fu_images), p(self._fu_ws), p(pk.G),
                                         p(loss_part), C.c_int(aligned), _lib.stream_ptr()), "dqn_fused_update")

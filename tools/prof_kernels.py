@@ -56,13 +56,14 @@ for _ in range(max(2, REPS // 4)):
 torch.cuda.synchronize()
 del harness
 env.exit()
-if os.environ.get("PROF_DQN", "1") != "0":          # configs[4]: one sampled replay step of 32768 rows through the DQN kernels
+if os.environ.get("PROF_DQN", "1") != "0":          # configs[4]: DQN updates of PROF_DQN_MB sampled replay steps x 32768 rows
     from fly_bproject_amd.dqn import DQN
     import contextlib
     import io
     with contextlib.redirect_stdout(io.StringIO()):
-        agent = DQN(make_args(32768, dqn_mini_batch_size=4, replay_steps=8))
-        for _ in range(6):
+        mb = int(os.environ.get("PROF_DQN_MB", "4"))        # sampled steps per update (summarize_pmc.py reads the same variable)
+        agent = DQN(make_args(32768, dqn_mini_batch_size=mb, replay_steps=2 * mb))
+        for _ in range(mb + 2):
             agent.run()
         for _ in range(REPS // 4 + 1):
             agent.update()
