@@ -43,19 +43,17 @@ ok = (s[:, 13] > 0)
 print("workgroups stamped: %d; cycles per tile %.0f" % (ok.sum(), d[ok].sum(1).mean()))
 for i, nm in enumerate(names):
     print("  %-30s %8.0f" % (nm, d[ok][:, i].mean()))
-fine = ["L1 GEMM a", "L1 GEMM b (+ epilogue a)", "L1 epilogue b", "barrier", "L2 GEMM a", "L2 GEMM b (+ epilogue a)", "L2 epilogue b", "barrier",
-        "L3 GEMM", "partials + barrier"]
+fine = ["L1 GEMM a", "L1 GEMM b (+ L1 epilogue a)", "barrier", "L2 GEMM a (+ L1 epilogue b, barrier inside)", "L2 GEMM b (+ L2 epilogue a)",
+        "head requests", "L3 GEMM (+ L2 epilogue b)", "partials + barrier"]
 for ps, (base, c0) in enumerate(((16, 1), (32, 6))):
     t = s[ok].astype(np.float64)
-    seq = [t[:, c0], t[:, base + 0], t[:, base + 1], t[:, base + 2], t[:, c0 + 1], t[:, base + 3], t[:, base + 4], t[:, base + 5],
-           t[:, c0 + 2], t[:, base + 6], t[:, c0 + 3]]
+    seq = [t[:, c0], t[:, base + 0], t[:, base + 1], t[:, c0 + 1], t[:, base + 3], t[:, base + 4], t[:, c0 + 2], t[:, base + 6], t[:, c0 + 3]]
     print("  inside the %s pass (wave 0):" % ("target", "online")[ps])
     for i, nm in enumerate(fine):
-        print("    %-28s %8.0f" % (nm, (seq[i + 1] - seq[i]).mean()))
+        print("    %-44s %8.0f" % (nm, (seq[i + 1] - seq[i]).mean()))
 t = s[ok].astype(np.float64)
 seq = [t[:, 11], t[:, 48], t[:, 49], t[:, 50], t[:, 51], t[:, 12]]
 print("  inside dA1 / dZ1 / dW1 (wave 0):")
-for i, nm in enumerate(["GEMM a", "GEMM b (+ dZ1 epilogue a)", "dZ2 image out", "dW1 a (+ dZ1 epilogue b)", "dW1 b"]):
-    print("    %-28s %8.0f" % (nm, (seq[i + 1] - seq[i]).mean()))
-print("  H1 image out (start of the dA2 phase) %8.0f" % (t[:, 52] - t[:, 10]).mean())
+for i, nm in enumerate(["GEMM a (+ dZ2 epilogue b, barrier inside), db2 b", "GEMM b (+ dZ1 epilogue a)", "dZ2 image out", "dW1 a (+ dZ1 epilogue b)", "dW1 b"]):
+    print("    %-50s %8.0f" % (nm, (seq[i + 1] - seq[i]).mean()))
 agent.exit()
