@@ -200,6 +200,46 @@ def test_dqn_td_gradient_matches_autograd(fused, B):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("parts,n,skew", [(5, 4096, 0), (5, 4096, 1), (3, 96, 1), (1, 32, 0)])
+def test_dqn_fused_update_over_chunks_and_misaligned_rows(parts, n, skew):
+    """dqn_fused_update on several sampled steps: 5 x 4096 rows = 640 tiles, so workgroups walk up to three tiles across chunk
+    boundaries (rows and scalars of the NEXT tile are requested a tile ahead); `skew` = 1 puts every row block one row into its
+    allocation (292 bytes: not 16-byte aligned), which takes the plain-load path instead of LDS-DMA; 32 rows = one tile, one
+    workgroup.  Against torch autograd on the concatenated batch."""
+    torch.manual_seed(11)
+    B = parts * n
+    d = _bare_dqn(rows=B, fused=True)
+    with torch.no_grad():
+        for p_ in d.q_target.parameters():
+            p_.add_(0.05 * torch.randn_like(p_))
+    d.packed.refresh()
+    chunks = []
+    for _ in range(parts):
+        obs = torch.randn(n + skew, 73, device="cuda:0")[skew:]; nxt = torch.randn(n + skew, 73, device="cuda:0")[skew:]
+        act = (torch.rand(n + skew, device="cuda:0") * 2 - 1)[skew:]
+        rew = (torch.randn(n + skew, device="cuda:0") * 2)[skew:]; done = (torch.rand(n + skew, device="cuda:0") > 0.1).float()[skew:]
+        assert obs.is_contiguous() and (skew == 0) == (obs.data_ptr() % 16 == 0)
+        chunks.append((obs, act, rew, nxt, done))
+    obs, act, rew, nxt, done = (torch.cat([c[i] for c in chunks]) for i in range(5))
+    idx = torch.round(0.5 * (act + 1) * 17).long()
+    q_val = d.q(obs)[torch.arange(B), idx]
+    with torch.no_grad():
+        target = rew + 0.99 * d.q_target(nxt).max(1)[0] * done
+    loss = torch.nn.functional.smooth_l1_loss(q_val, target)
+    grads = torch.autograd.grad(loss, list(d.q.parameters()))
+    got_loss = d.update(chunks)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(got_loss), float(loss), rtol=2e-5)
+    G = d.packed.G
+    views = {"net.0.weight": G[:256 * 80].view(256, 80)[:, :73], "net.0.bias": G[20480:20736],
+             "net.2.weight": G[20736:86272].view(256, 256), "net.2.bias": G[86272:86528],
+             "net.4.weight": G[86528:94720].view(32, 256)[:18], "net.4.bias": G[94720:94738]}
+    for (name, _), want in zip(d.q.named_parameters(), grads):
+        scale = float(want.abs().max()) + 1e-12
+        assert float((views[name] - want).abs().max()) <= 2e-4 * scale + 1e-9, name
+
+
+@pytest.mark.gpu
 def test_dqn_runs_end_to_end():
     from fly_bproject_amd.dqn import DQN
     from tests.hip_helpers import make_args
