@@ -240,6 +240,47 @@ def test_dqn_fused_update_over_chunks_and_misaligned_rows(parts, n, skew):
 
 
 @pytest.mark.gpu
+def test_dqn_fused_update_at_full_size_is_deterministic_and_linear():
+    """BASELINE configs[4]'s row count per sampled step (32768), eight sampled steps: (i) two runs on the same inputs leave the same
+    packed gradient and per-tile loss sums bit for bit (fixed-order reductions everywhere: no atomics); (ii) the gradient of the batch
+    is the mean of the gradients of its halves (the update is a sum over rows scaled by 1 / B: any row lost or doubled at a tile,
+    chunk or workgroup boundary breaks this), to summation-order rounding; (iii) it agrees with the per-step fp32-MFMA launches."""
+    torch.manual_seed(3)
+    n, parts = 32768, 8
+    d = _bare_dqn(rows=n, fused=True)
+    with torch.no_grad():
+        for p_ in d.q_target.parameters():
+            p_.add_(0.05 * torch.randn_like(p_))
+    d.packed.refresh()
+    chunks = [(torch.randn(n, 73, device="cuda:0"), torch.rand(n, device="cuda:0") * 2 - 1, torch.randn(n, device="cuda:0") * 2,
+               torch.randn(n, 73, device="cuda:0"), (torch.rand(n, device="cuda:0") > 0.1).float()) for _ in range(parts)]
+    p0 = [t.clone() for t in (d.packed.P, d.packed.P_tgt, d.packed.exp_avg, d.packed.exp_avg_sq, d.packed.step)]
+
+    def restore():      # the update also steps Adam and the target: put the networks back
+        for dst, src in zip((d.packed.P, d.packed.P_tgt, d.packed.exp_avg, d.packed.exp_avg_sq, d.packed.step), p0):
+            dst.copy_(src)
+        d.packed.refresh()
+
+    def grad(cs, fused=True):
+        restore()
+        d.fused_update = fused
+        loss = d.update(cs)
+        torch.cuda.synchronize()
+        return d.packed.G.clone(), float(loss)
+    g1, l1 = grad(chunks)
+    g2, l2 = grad(chunks)
+    assert torch.equal(g1, g2) and l1 == l2
+    ga, la = grad(chunks[:parts // 2])
+    gb, lb = grad(chunks[parts // 2:])
+    m = d.packed.grad_mask > 0
+    scale = float(g1[m].abs().max())
+    assert float((0.5 * (ga + gb) - g1)[m].abs().max()) <= 2e-5 * scale
+    assert abs(0.5 * (la + lb) - l1) <= 2e-5 * abs(l1)
+    g3, l3 = grad(chunks, fused=False)
+    assert float((g3 - g1)[m].abs().max()) <= 2e-4 * scale and abs(l3 - l1) <= 2e-5 * abs(l1)
+
+
+@pytest.mark.gpu
 def test_dqn_runs_end_to_end():
     from fly_bproject_amd.dqn import DQN
     from tests.hip_helpers import make_args

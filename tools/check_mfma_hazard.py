@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Lint of the compiled kernels for the hazard inline-asm MFMAs are exposed to: hipcc pads "vector instruction writes a VGPR -> MFMA
+reads it as an operand" for its OWN MFMAs, but an `asm volatile("v_mfma...")` is an opaque instruction to it -- if register
+allocation makes it assemble an operand tuple with a v_mov (or any VALU) right in front of the asm, the MFMA may read the OLD register
+(timing dependent: run-to-run differences in the last bits).  For every csrc/*.hip: compile to ISA, and for every v_mfma inside an
+#ASMSTART / #ASMEND block report VALU writes to its A / B / C operand registers within the last WAIT wait states.
+
+    python tools/check_mfma_hazard.py [file.hip ...]        exit code 1 if anything is found
+"""
+import glob
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(REPO, "fly_bproject_amd", "csrc")
+WAIT = 4
+
+
+def regs(tok):
+    tok = tok.strip().rstrip(",")
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def check(path):
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-I" + os.path.join(REPO, "include"),
+                               "-I" + CSRC, "-Wno-unused-function", "-S", "--cuda-device-only", "-o", out, path], stderr=subprocess.DEVNULL)
+        lines = open(out).read().split("\n")
+    found = []
+    in_asm = False
+    hist = []            # (wait states ago accumulates, written regs, text) of recent instructions
+    func = "?"
+    for ln, raw in enumerate(lines, 1):
+        s = raw.strip()
+        if s.endswith(":") and not s.startswith(".") and not s.startswith(";"):
+            func = s[:-1][:60]
+        if "#ASMSTART" in s:
+            in_asm = True
+            continue
+        if "#ASMEND" in s:
+            in_asm = False
+            continue
+        if not s or s.startswith(";") or s.startswith("."):
+            continue
+        op = s.split()[0]
+        if op == "s_nop":
+            n = int(s.split()[1]) + 1
+            hist = [(w + n, r, t) for (w, r, t) in hist]
+            continue
+        args = s[len(op):].split(",")
+        if op.startswith("v_mfma") and in_asm:
+            src = regs(args[1]) | regs(args[2]) | (regs(args[3]) if len(args) > 3 else set())      # A, B and the accumulator input
+            for w, r, t in hist:
+                if w < WAIT and r & src:
+                    found.append((os.path.basename(path), func, ln, t, s))
+        # every instruction is one wait state
+        hist = [(w + 1, r, t) for (w, r, t) in hist if w + 1 < WAIT + 2]
+        if op.startswith("v_") and not op.startswith("v_mfma") and not op.startswith("v_cmp"):
+            hist.append((0, regs(args[0]), s))
+    return found
+
+
+def main():
+    files = sys.argv[1:] or sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    bad = []
+    for f in files:
+        bad += check(f)
+    for b in bad:
+        print("%s %s line %d: `%s` in front of `%s`" % b)
+    print("%d hazard(s) in %d file(s)" % (len(bad), len(files)))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
