@@ -3,7 +3,9 @@
 reads it as an operand" for its OWN MFMAs, but an `asm volatile("v_mfma...")` is an opaque instruction to it -- if register
 allocation makes it assemble an operand tuple with a v_mov (or any VALU) right in front of the asm, the MFMA may read the OLD register
 (timing dependent: run-to-run differences in the last bits).  For every csrc/*.hip: compile to ISA, and for every v_mfma inside an
-#ASMSTART / #ASMEND block report VALU writes to its A / B / C operand registers within the last WAIT wait states.
+#ASMSTART / #ASMEND block report VALU writes to its A / B / C operand registers within the last WAIT wait states -- and, the other
+direction, any vector / LDS / memory instruction that reads such an MFMA's result within RESULT_WAIT wait states (what fs_mfma_settle
+is there for).
 
     python tools/check_mfma_hazard.py [file.hip ...]        exit code 1 if anything is found
 """
@@ -17,6 +19,7 @@ import tempfile
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(REPO, "fly_bproject_amd", "csrc")
 WAIT = 4
+RESULT_WAIT = 11          # an 8-pass MFMA's result -> a vector / memory instruction reading it
 
 
 def regs(tok):
@@ -37,6 +40,7 @@ def check(path):
     found = []
     in_asm = False
     hist = []            # (wait states ago accumulates, written regs, text) of recent instructions
+    res = []             # (wait states ago, result regs, text) of recent asm MFMAs: a non-MFMA reader needs RESULT_WAIT wait states
     func = "?"
     for ln, raw in enumerate(lines, 1):
         s = raw.strip()
@@ -54,6 +58,7 @@ def check(path):
         if op == "s_nop":
             n = int(s.split()[1]) + 1
             hist = [(w + n, r, t) for (w, r, t) in hist]
+            res = [(w + n, r, t) for (w, r, t) in res]
             continue
         args = s[len(op):].split(",")
         if op.startswith("v_mfma") and in_asm:
@@ -61,6 +66,18 @@ def check(path):
             for w, r, t in hist:
                 if w < WAIT and r & src:
                     found.append((os.path.basename(path), func, ln, t, s))
+        # the other direction: something that is not an MFMA reads an asm MFMA's result before it is written (fs_mfma_settle's job)
+        if not op.startswith("v_mfma") and (op.startswith("v_") or op.startswith("ds_") or op.startswith("global_") or op.startswith("scratch_")):
+            srcs = set()
+            for a in (args if (op.startswith("ds_write") or op.startswith("global_store") or op.startswith("scratch_store")) else args[1:]):
+                for tok in re.findall(r"v\[\d+:\d+\]|v\d+", a):
+                    srcs |= regs(tok)
+            for w, r, t in res:
+                if w < RESULT_WAIT and r & srcs:
+                    found.append((os.path.basename(path), func, ln, t, s))
+        res = [(w + 1, r, t) for (w, r, t) in res if w + 1 < RESULT_WAIT + 2]
+        if op.startswith("v_mfma") and in_asm:
+            res.append((0, regs(args[0]), s))
         # every instruction is one wait state
         hist = [(w + 1, r, t) for (w, r, t) in hist if w + 1 < WAIT + 2]
         if op.startswith("v_") and not op.startswith("v_mfma") and not op.startswith("v_cmp"):
