@@ -36,7 +36,7 @@ for rep in range(3):
     print("update of %d sampled steps x %d rows: %.2f ms (%.1f us per sampled step)" % (S, n, e0.elapsed_time(e1), e0.elapsed_time(e1) * 1e3 / S))
 lib.flyhip_debug_set_dqn_stamps(None)
 s = stamps.cpu().numpy().reshape(256, 64)
-names = ["target: rows in + x planes", "target L1", "target L2", "target L3 + partials", "target max, barrier", "online: rows in + x planes",
+names = ["target: input planes", "target L1", "target L2", "target L3 + partials", "online input planes + target max, barrier", "(online pass begins)",
          "online L1", "online L2", "online L3 + partials", "loss + dZ3", "dA2, dZ2, dW3, db", "dA1, dZ1, dW1", "image copy-out", ]
 d = np.diff(s[:, :14], axis=1).astype(np.float64)
 ok = (s[:, 13] > 0)
