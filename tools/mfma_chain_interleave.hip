@@ -115,7 +115,7 @@ double run(const uint16_t* W)
     return per;
 }
 
-int main()
+static int main_round4()
 {
     uint16_t* W;
     const size_t halves = (size_t)KSTEPS * 4 * 1536;            // 196 KiB: layer 2's term planes
@@ -126,5 +126,207 @@ int main()
     run<0, true, 6>(W); run<3, true, 6>(W);
     run<0, true, 2>(W);
     (void)hipFree(W);
+    return 0;
+}
+
+// =====================================================================================================================
+// Round 5: WHICH ARITHMETIC, WHICH MFMA SHAPE?  The same chain GEMM (K = 256, the same 32 x 32 output tile per wave, one wave per
+// SIMD on all 256 CUs, every CU streaming the same weight planes from L2, activations from LDS), on RANDOM operand bits, as
+//   b3/32x32x16  three bf16 terms per operand, six products per k-step (2 into `hi`, 4 into `lo`): what ships
+//   h2/32x32x16  two fp16 terms per operand, three products (h0 h0 -> hi; h0 h1, h1 h0 -> lo): DESIGN.md section 9.1
+//   b3/16x16x32, h2/16x16x32  the same two on the 16x16x32 shape (four accumulators of 4 registers per 32 x 32 tile, k-steps of 32)
+// Reported per variant: shader cycles per 16 k (s_memtime), the in-kernel clock (delta s_memtime / delta s_memrealtime x 100 MHz,
+// median over workgroups, after >= 1 s of back-to-back launches of that variant) and WALL time per 16 k per wave (HIP events):
+// the microarchitecture guide's DVFS item 7 says the chip may hold a higher clock on one shape, so cycles alone do not rank them.
+//   ./mfma_chain_interleave arith
+#include <vector>
+#include <algorithm>
+#include <cstring>
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <bool F16> __device__ __forceinline__ void mf32(f32x16& acc, const f32x4v& a, const f32x4v& b)
+{
+    if (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+template <bool F16> __device__ __forceinline__ void mf16(f32x4v& acc, const f32x4v& a, const f32x4v& b)
+{
+    if (F16) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
+// out[wg] = {cycles, realtime ticks (100 MHz)}
+template <bool F16, bool S16>
+__global__ __launch_bounds__(256, 1) void ka(const uint16_t* __restrict__ W, const uint16_t* __restrict__ A, unsigned long long* out, int gemms)
+{
+    constexpr int NP = F16 ? 2 : 3;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];          // NP planes [32][PITCH]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < NP * 32 * PITCH; i += 256) lds[i] = A[i];
+    __syncthreads();
+    unsigned long long t0, t1, r0, r1;
+    if (!S16) {
+        f32x16 hi, lo;
+        for (int i = 0; i < 16; ++i) { hi[i] = 0.f; lo[i] = 0.f; }
+        const uint16_t* arow = lds + (lane & 31) * PITCH + (lane >> 5) * 8;
+        const uint16_t* bp = W + (long)wave * (NP * 512) + lane * 8;       // [k-step][wave][plane][lane * 8]
+        constexpr int RING = 4;
+        f32x4v b[RING][NP], a[2][NP];
+        auto wload = [&](f32x4v (&f)[NP], int kb) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) f[p] = *reinterpret_cast<const f32x4v*>(bp + (long)kb * 4 * (NP * 512) + p * 512);
+        };
+        auto aload = [&](f32x4v (&f)[NP], int kb) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) f[p] = *reinterpret_cast<const f32x4v*>(arow + 16 * kb + p * 32 * PITCH);
+        };
+        t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime();
+        for (int g = 0; g < gemms; ++g) {
+#pragma unroll
+            for (int s = 0; s < RING; ++s) wload(b[s], s);
+            aload(a[0], 0); aload(a[1], 1);
+#pragma unroll
+            for (int kb = 0; kb < KSTEPS; ++kb) {
+                const int s = kb % RING, sa = kb & 1;
+                __builtin_amdgcn_sched_barrier(0);
+                if (F16) {
+                    mf32<F16>(lo, b[s][0], a[sa][1]); mf32<F16>(hi, b[s][0], a[sa][0]); mf32<F16>(lo, b[s][1], a[sa][0]);
+                } else {
+                    mf32<F16>(lo, b[s][0], a[sa][NP - 1]); mf32<F16>(hi, b[s][0], a[sa][0]);
+                    mf32<F16>(lo, b[s][NP - 1], a[sa][0]); mf32<F16>(lo, b[s][1], a[sa][1]);
+                    mf32<F16>(lo, b[s][0], a[sa][1]); mf32<F16>(lo, b[s][1], a[sa][0]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (kb + RING < KSTEPS) wload(b[s], kb + RING);
+                if (kb + 2 < KSTEPS) aload(a[sa], kb + 2);
+            }
+        }
+        t1 = __builtin_amdgcn_s_memtime(); r1 = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(hi), "+v"(lo));
+        float sum = 0.f;
+        for (int i = 0; i < 16; ++i) sum += hi[i] + lo[i];
+        if (sum == 12345.678f) out[0] = 0;
+    } else {
+        // 16x16x32: operand fragment = 16 rows x 32 k, lane l holds row l & 15, k 8 (l >> 4) .. + 7; the 32 x 32 tile is four
+        // accumulators [column half][row half]; a k-step is 32 wide: per plane two weight fragments and two activation fragments
+        f32x4v hi[2][2], lo[2][2];
+        for (int c = 0; c < 2; ++c) for (int r = 0; r < 2; ++r) for (int i = 0; i < 4; ++i) { hi[c][r][i] = 0.f; lo[c][r][i] = 0.f; }
+        const uint16_t* arow = lds + (lane & 15) * PITCH + (lane >> 4) * 8;
+        const uint16_t* bp = W + (long)wave * (NP * 1024) + lane * 8;      // [k32-step][wave][plane][column half][lane * 8]
+        constexpr int K32 = KSTEPS / 2, RING = 2;
+        f32x4v b[RING][NP][2], a[2][NP][2];
+        auto wload = [&](f32x4v (&f)[NP][2], int kb) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) f[p][c] = *reinterpret_cast<const f32x4v*>(bp + (long)kb * 4 * (NP * 1024) + p * 1024 + c * 512);
+        };
+        auto aload = [&](f32x4v (&f)[NP][2], int kb) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) f[p][r] = *reinterpret_cast<const f32x4v*>(arow + 32 * kb + r * 16 * PITCH + p * 32 * PITCH);
+        };
+        t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime();
+        for (int g = 0; g < gemms; ++g) {
+#pragma unroll
+            for (int s = 0; s < RING; ++s) wload(b[s], s);
+            aload(a[0], 0); aload(a[1], 1);
+#pragma unroll
+            for (int kb = 0; kb < K32; ++kb) {
+                const int s = kb % RING, sa = kb & 1;
+                __builtin_amdgcn_sched_barrier(0);
+#define T4(ACC, PW, PX)                                                                                                           \
+    mf16<F16>(ACC[0][0], b[s][PW][0], a[sa][PX][0]); mf16<F16>(ACC[0][1], b[s][PW][0], a[sa][PX][1]);                                    \
+    mf16<F16>(ACC[1][0], b[s][PW][1], a[sa][PX][0]); mf16<F16>(ACC[1][1], b[s][PW][1], a[sa][PX][1]);
+                if (F16) { T4(lo, 0, 1) T4(hi, 0, 0) T4(lo, 1, 0) }
+                else { T4(lo, 0, NP - 1) T4(hi, 0, 0) T4(lo, NP - 1, 0) T4(lo, 1, 1) T4(lo, 0, 1) T4(lo, 1, 0) }
+#undef T4
+                __builtin_amdgcn_sched_barrier(0);
+                if (kb + RING < K32) wload(b[s], kb + RING);
+                if (kb + 2 < K32) aload(a[sa], kb + 2);
+            }
+        }
+        t1 = __builtin_amdgcn_s_memtime(); r1 = __builtin_amdgcn_s_memrealtime();
+        float sum = 0.f;
+        for (int c = 0; c < 2; ++c) for (int r = 0; r < 2; ++r) {
+            asm volatile("s_nop 7\n\ts_nop 7" : "+v"(hi[c][r]), "+v"(lo[c][r]));
+            for (int i = 0; i < 4; ++i) sum += hi[c][r][i] + lo[c][r][i];
+        }
+        if (sum == 12345.678f) out[0] = 0;
+    }
+    if (tid == 0) { out[2 * blockIdx.x] = t1 - t0; out[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+static uint16_t rnd16(bool f16)
+{
+    const unsigned r = (unsigned)rand();
+    if (f16) return (uint16_t)(((r >> 15) & 1) << 15 | (8 + (r >> 10) % 15) << 10 | (r & 1023));     // exponents 8 .. 22 of 31
+    return (uint16_t)(((r >> 15) & 1) << 15 | (120 + (r >> 7) % 15) << 7 | (r & 127));               // exponents 120 .. 134 of 255
+}
+
+struct ArithRow { double cyc, ghz, wall_ns; };
+template <bool F16, bool S16>
+static ArithRow run_arith(const char* name)
+{
+    constexpr int NP = F16 ? 2 : 3;
+    const int wgs = 256, gemms = 4000;
+    const size_t wh = (size_t)KSTEPS * 4 * NP * 512, ah = (size_t)NP * 32 * PITCH;
+    std::vector<uint16_t> hw(wh), ha(ah);
+    for (auto& v : hw) v = rnd16(F16);
+    for (auto& v : ha) v = rnd16(F16);
+    uint16_t *W, *A;
+    unsigned long long* out;
+    (void)hipMalloc(&W, wh * 2); (void)hipMalloc(&A, ah * 2); (void)hipMalloc(&out, wgs * 16);
+    (void)hipMemcpy(W, hw.data(), wh * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(A, ha.data(), ah * 2, hipMemcpyHostToDevice);
+    const size_t ldsb = ah * 2;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ka<F16, S16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    // >= 1 s of back-to-back launches of this variant, then the timed ones
+    (void)hipEventRecord(e0);
+    float ms = 0.f;
+    int warm = 0;
+    while (ms < 1000.f) {
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((ka<F16, S16>), dim3(wgs), dim3(256), ldsb, 0, W, A, out, gemms);
+        warm += 10;
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
+    }
+    const int reps = 20;
+    (void)hipEventRecord(e0);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((ka<F16, S16>), dim3(wgs), dim3(256), ldsb, 0, W, A, out, gemms);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(2 * wgs);
+    (void)hipMemcpy(h.data(), out, wgs * 16, hipMemcpyDeviceToHost);
+    std::vector<double> cyc(wgs), ghz(wgs);
+    for (int i = 0; i < wgs; ++i) { cyc[i] = (double)h[2 * i]; ghz[i] = (double)h[2 * i] / (double)h[2 * i + 1] * 0.1; }
+    std::sort(cyc.begin(), cyc.end()); std::sort(ghz.begin(), ghz.end());
+    ArithRow r;
+    r.cyc = cyc[wgs / 2] / (gemms * (double)KSTEPS);
+    r.ghz = ghz[wgs / 2];
+    r.wall_ns = ms * 1e6 / reps / (gemms * (double)KSTEPS);
+    printf("%-14s %7.1f cycles per 16 k  | in-kernel clock %.3f GHz | wall %6.1f ns per 16 k (%d warm-up launches, %d timed)\n", name, r.cyc,
+           r.ghz, r.wall_ns, warm, reps);
+    (void)hipFree(W); (void)hipFree(A); (void)hipFree(out);
+    return r;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 2 || strcmp(argv[1], "arith") != 0) return main_round4();
+    srand(5);
+    printf("chain GEMM replica, K = 256, one 32 x 32 output tile per wave, weights streamed from L2, random operand bits\n");
+    const ArithRow a = run_arith<false, false>("b3 / 32x32x16");
+    const ArithRow b = run_arith<true, false>("h2 / 32x32x16");
+    const ArithRow c = run_arith<false, true>("b3 / 16x16x32");
+    const ArithRow d = run_arith<true, true>("h2 / 16x16x32");
+    // once more in the other order (DVFS / thermal drift between the first and the last variant)
+    const ArithRow d2 = run_arith<true, true>("h2 / 16x16x32");
+    const ArithRow c2 = run_arith<false, true>("b3 / 16x16x32");
+    const ArithRow b2 = run_arith<true, false>("h2 / 32x32x16");
+    const ArithRow a2 = run_arith<false, false>("b3 / 32x32x16");
+    printf("wall, relative to b3 / 32x32x16 (both passes): h2/32 %.3f %.3f | b3/16 %.3f %.3f | h2/16 %.3f %.3f\n", b.wall_ns / a.wall_ns,
+           b2.wall_ns / a2.wall_ns, c.wall_ns / a.wall_ns, c2.wall_ns / a2.wall_ns, d.wall_ns / a.wall_ns, d2.wall_ns / a2.wall_ns);
     return 0;
 }
