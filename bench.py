@@ -39,11 +39,13 @@ def parse():
                     help="per-optimizer-step gradient exchange of N > 1 ranks: rccl (default) = torch.distributed.all_reduce; "
                          "p2p = the one-shot peer-to-peer kernel; auto = p2p if its start-up self-test against RCCL passes on "
                          "this node, else RCCL.  (--p2p_variant times the p2p kernel beside an rccl run.)")
-    ap.add_argument("--gemm", choices=["bf16x3", "f32"], default=os.environ.get("FLY_GEMM", "bf16x3"),
-                    help="arithmetic of every MLP GEMM of `value`: bf16x3 = fp32 operands split exactly into three bf16 terms, six "
-                         "product terms on the bf16 matrix pipe, fp32 accumulate (held to the reference's golden vectors at the "
-                         "fp32 tolerances: tests/test_mlp_train_gpu.py, tests/test_ppo_gpu.py); f32 = v_mfma_f32_32x32x2_f32.  The "
-                         "other one is measured too and reported as the labelled secondary figure")
+    ap.add_argument("--gemm", choices=["f16x2", "bf16x3", "f32"], default=os.environ.get("FLY_GEMM", "f16x2"),
+                    help="arithmetic of the MLP GEMMs of `value`: f16x2 (default) = bf16x3 for the rollout's policy and the critic pass, "
+                         "and the optimizer-step gradient (82 %% of an iteration) in the two-term fp16 split with three product terms "
+                         "and per-class power-of-two scales (csrc/mlp_fused_h2.inc); bf16x3 = fp32 operands split exactly into three "
+                         "bf16 terms, six product terms, for every GEMM; f32 = v_mfma_f32_32x32x2_f32.  All three are held to the "
+                         "reference's golden vectors at the fp32 tolerances (tests/test_mlp_train_gpu.py, tests/test_ppo_gpu.py) and to "
+                         "fp64 (tests/test_fused_h2_gpu.py); the others are measured too and reported as labelled secondary figures")
     ap.add_argument("--p2p_variant", action="store_true",
                     help="with --dp_allreduce rccl: also open, self-test and TIME the one-shot peer-to-peer exchange as a labelled "
                          "variant (`grad_exchange_variants_us.p2p`).  Off by default: its cross-GPU leg has never run on xGMI "
@@ -263,7 +265,62 @@ class RolloutAllHarness:
 
 
 def mlp_peak_for(gemm):
+    """Roofline of the ALGORITHMIC FLOP of an MLP GEMM: the dense 16-bit MFMA peak over the product terms per multiply-add
+    (bf16x3: six; f16x2: three -- fp16 runs at the bf16 rate), or the fp32 matrix peak."""
+    if gemm == "f16x2":
+        return round(PEAK_BF16_MFMA_TFLOPS / 3.0, 1)
     return PEAK_F32_MFMA_TFLOPS if gemm == "f32" else round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)
+
+
+def _round_key(path):
+    """Sort key of a profiles/ file by its round tag (r4l < r5a < r10b: the number numerically, then the letter), then by name."""
+    import re
+    m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(path))
+    return (int(m.group(1)), m.group(2), os.path.basename(path)) if m else (-1, "", os.path.basename(path))
+
+
+def latest_profile(pattern):
+    """The newest profiles/<round tag>_<pattern> by round tag (natural order), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", pattern)), key=_round_key)
+    return files[-1] if files else None
+
+
+def fused_step_clock(pol, batch, h2):
+    """In-kernel clock of the fused optimizer-step kernel (its STAMP instantiation: s_memtime / s_memrealtime of every workgroup at
+    kernel entry and after its slab is written), after the timed launches have warmed the chip: GHz, or None."""
+    import ctypes as C
+    from fly_bproject_amd import _lib
+    try:
+        lib = _lib.load()
+        x, act, olp, adv, tgt, var = batch
+        rows = x.shape[0]
+        stamps = torch.zeros(256 * 64 * 32, dtype=torch.int64, device="cuda:0")
+        p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+        arr = (C.c_void_p * 8)(stamps.data_ptr(), None, None, None, None, None, None, None)
+        if pol._fused_ws is None:
+            return None
+        # the chip holds its clock down under this load: stamp behind a long run of back-to-back product launches, with no idle
+        # gap in between (microarchitecture guide, DVFS item 6)
+        for _ in range(400):
+            pol.minibatch_grad(x, act, olp, adv, tgt, var, 0.2, fuse_norm=False)
+        for _ in range(3):
+            if h2:
+                _lib.check(lib.mlp_fused_grad_h2(p(pol.P), p(pol.PH), p(pol.PTH), p(pol.h2_scales), p(pol.h2_overflow), 1, p(x), rows, p(act),
+                                                 p(olp), p(adv), p(tgt), p(var), C.c_float(1.0 / rows), C.c_float(0.2), p(pol._fused_ws),
+                                                 p(pol.G), None, None, None, p(pol.loss_part), arr, _lib.stream_ptr()), "stamp")
+            else:
+                _lib.check(lib.mlp_fused_grad(p(pol.P), p(pol.PB), p(pol.PTB), p(x), rows, p(act), p(olp), p(adv), p(tgt), p(var),
+                                              C.c_float(1.0 / rows), C.c_float(0.2), p(pol._fused_ws), p(pol.G), None, None, None,
+                                              p(pol.loss_part), arr, _lib.stream_ptr()), "stamp")
+        torch.cuda.synchronize()
+        s = stamps.cpu().numpy().reshape(256, 64, 32)
+        whole = (s[:, 63, 1] - s[:, 62, 0]).astype("float64")
+        real_us = ((s[:, 63, 2] & 0xffffffffffff) - (s[:, 62, 1] & 0xffffffffffff)).astype("float64") / 100.0
+        ok = real_us > 0
+        return round(float((whole[ok] / real_us[ok]).mean() / 1e3), 3) if ok.any() else None
+    except Exception:       # noqa: BLE001  (a diagnostic: never cost the line)
+        return None
 
 
 def kernel_rooflines(num_envs, T, reps, gemm="f32"):
@@ -283,6 +340,7 @@ def kernel_rooflines(num_envs, T, reps, gemm="f32"):
     pol = PackedPolicy(net, "cuda:0")
     pol.init_training(rows)
     pol.gemm = gemm
+    h2 = pol.h2_live()
     x = torch.randn(rows, 73, device="cuda:0")
     act = torch.rand(rows, 18, device="cuda:0") * 2 - 1
     olp = torch.randn(rows, device="cuda:0") - 20
@@ -290,6 +348,8 @@ def kernel_rooflines(num_envs, T, reps, gemm="f32"):
     var = torch.full((18,), 0.2, device="cuda:0")
     p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
     s, d = pol.saves, pol.dz
+    if h2:
+        pol.calibrate_h2(x, act, olp, adv, tgt, var, 0.2)
     pol.minibatch_grad(x, act, olp, adv, tgt, var, 0.2)
     flags = torch.zeros((rows + 31) // 32, dtype=torch.int32, device="cuda:0")
     err = torch.zeros(1, dtype=torch.int32, device="cuda:0")
@@ -303,8 +363,12 @@ def kernel_rooflines(num_envs, T, reps, gemm="f32"):
                                  coherent, _lib.stream_ptr())
     fused = pol.fused_step and pol.gemm == "bf16x3"
     t_fused = None
+    fused_clock = None
     if fused:       # the loop's optimizer-step gradient: ONE persistent launch (forward + loss + dX chain + dW) + the slab reduction
         t_fused = _time_launches(lambda: pol.minibatch_grad(x, act, olp, adv, tgt, var, 0.2, fuse_norm=True), reps)
+        fused_clock = fused_step_clock(pol, (x, act, olp, adv, tgt, var), h2)
+        if h2:
+            assert int(pol.h2_overflow.item()) == 0, "the timed fp16x2 launches overflowed"
     t_fb = _time_launches(lambda: fwd_bwd(1 if pol.handoff == "sc1" else 0), reps)
     # A/B of the tile hand-off inside the launch: sc1 write-through + L1-bypassing loads vs plain accesses on one XCD
     t_fb_alt = _time_launches(lambda: fwd_bwd(0 if pol.handoff == "sc1" else 1), reps)
@@ -408,17 +472,19 @@ def kernel_rooflines(num_envs, T, reps, gemm="f32"):
         hbm("mlp_adam_apply_kernel (clip + Adam + fragment refresh)", t_adam, 74272 * 4 * 10, 75),
         hbm("ppo_td_gae_kernel (T=%d x %d envs)" % (T, num_envs), t_gae, 20 * Tn, 1),
     ]
+    fused_kernel = ("mlp_fused_step_h2_kernel", "mlp_grad_reduce_h2_kernel") if h2 else ("mlp_fused_step_kernel", "mlp_grad_reduce_kernel")
     if fused:
         # algorithmic FLOP of the whole minibatch gradient (forward + dX chain + dW); share 0 entries above are the three-launch
-        # A/B path (FLY_FUSED_STEP=0), timed on the same data
-        ks.insert(0, mfma("mlp_fused_step_kernel (forward + loss + dX + dW, %d rows; + mlp_grad_reduce_kernel)" % rows, t_fused,
-                          (MLP_FWD_FLOP + MLP_BWD_DX_FLOP + MLP_GRAD_W_FLOP) * rows, 75))
+        # A/B path (FLY_FUSED_STEP=0), timed on the same data.  fp16x2: three fp16 MFMA terms per product -> dense 16-bit peak / 3
+        ks.insert(0, mfma("%s (forward + loss + dX + dW, %d rows; + %s)" % (fused_kernel[0], rows, fused_kernel[1]), t_fused,
+                          (MLP_FWD_FLOP + MLP_BWD_DX_FLOP + MLP_GRAD_W_FLOP) * rows, 75, peak=mlp_peak_for("f16x2" if h2 else pol.gemm)))
+        ks[0]["arithmetic"] = "f16x2" if h2 else pol.gemm
+        ks[0]["in_kernel_clock_ghz"] = fused_clock
     # the env kernel's REAL bound is vector-instruction issue, not HBM: instructions per wave (committed PMC pass,
     # profiles/*_valu.json) x 4 issue cycles at one wave per SIMD, against the measured launch
     try:
-        import glob
-        vf = sorted(glob.glob(os.path.join(REPO, "profiles", "*_valu.json")))
-        if vf:
+        vf = [latest_profile("*_valu.json")]
+        if vf[0]:
             vj = json.load(open(vf[-1]))
             ipw = vj["fly_kernel<63>"]["valu_insts_per_wave"]
             clk = vj.get("clock_ghz", 2.1)
@@ -441,12 +507,11 @@ def kernel_rooflines(num_envs, T, reps, gemm="f32"):
         pass
     # HBM bytes per launch from the committed PMC passes (profiles/*_traffic.json, produced by
     # tools/summarize_pmc.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of the same kernels)
-    traffic = {}
+    traffic, traffic_file = {}, None
     try:
-        import glob
-        files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_traffic.json")))
-        if files:
-            traffic = json.load(open(files[-1]))
+        traffic_file = latest_profile("*_traffic.json")
+        if traffic_file:
+            traffic = json.load(open(traffic_file))
     except Exception:
         traffic = {}
     grids = {"fly_kernel<63> (fly_step)": ("fly_kernel<63>", ((num_envs + 31) // 32) * 256),
@@ -456,15 +521,16 @@ def kernel_rooflines(num_envs, T, reps, gemm="f32"):
              "mlp_forward_kernel (policy + sample, %d rows)" % num_envs: ("mlp_forward_kernel", ((num_envs + 31) // 32) * 256),
              "mlp_grad_w_kernel (+reduce)": ("mlp_grad_w_b3_kernel" if pol.gemm == "bf16x3" else "mlp_grad_w_kernel", 256 * 1024)}
     if fused:
-        grids[ks[0]["kernel"]] = ("mlp_fused_step_kernel", 256 * 256)
+        grids[ks[0]["kernel"]] = (fused_kernel[0], 256 * 256)
     for k in ks:
         key = grids.get(k["kernel"])
         if key:
             t = traffic.get("%s@%d" % key)
             if t:
                 k["traffic"] = t["hbm_bytes_per_launch"]
-                if key[0] == "mlp_fused_step_kernel":       # the entry times the reduction with it: add its bytes
-                    r = next((v for kk, v in sorted(traffic.items()) if kk.startswith("mlp_grad_reduce_kernel@")), None)
+                k["traffic_source"] = os.path.basename(traffic_file) + " (committed PMC passes of that build, not live)"
+                if key[0] == fused_kernel[0]:       # the entry times the reduction with it: add its bytes
+                    r = next((v for kk, v in sorted(traffic.items()) if kk.startswith(fused_kernel[1] + "@")), None)
                     if r:
                         k["traffic"] += r["hbm_bytes_per_launch"]
                         k["traffic_note"] = "fused launch + slab reduction"
@@ -692,8 +758,7 @@ def dqn_measure(n, mb, warmup, steps, kernel_reps):
         dtype = "bf16x3"
         # HBM bytes from the committed PMC passes (profiles/*_traffic.json: per launch of PROF_DQN_MB sampled steps -> scaled to `mb`)
         try:
-            import glob
-            files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_traffic.json")))
+            files = [f for f in [latest_profile("*_traffic.json")] if f]
             tr = json.load(open(files[-1])) if files else {}
             for k, nm in ((ks[0], "dqn_chain_kernel"), (ks[1], "dqn_dw2_kernel")):
                 t = next((v for kk, v in sorted(tr.items()) if kk.startswith(nm + "@") and "hbm_bytes_per_sampled_step" in v), None)
@@ -738,6 +803,11 @@ def dqn_bench(a):
 
 
 GEMM_LABEL = {
+    "f16x2": "the optimizer-step gradient (forward, loss, dX chain, dW of a minibatch: mlp_fused_grad_h2) with every fp32 operand as two "
+             "fp16 terms of its value times a per-tensor-class power of two, three product terms on v_mfma_f32_32x32x16_f16, fp32 "
+             "accumulate (error vs fp64 inside the fp32 MFMA chain's: tests/test_fused_h2_gpu.py, tools/bf16x3_gemm.hip; a value that "
+             "does not fit fp16 -> the step is refused on the device and redone in bf16x3); the rollout's policy and the critic pass "
+             "in bf16x3 (below)",
     "f32": "fp32 operands on v_mfma_f32_32x32x2_f32, fp32 accumulate",
     "bf16x3": "fp32 operands split exactly into three bf16 terms each, six product terms on v_mfma_f32_32x32x16_bf16, fp32 "
               "accumulate (error vs fp64 below the fp32 MFMA chain's: tools/bf16x3_gemm.hip) for EVERY MLP GEMM: rollout policy, "
@@ -877,29 +947,33 @@ def main():
     exchange_us = time_exchange(agent, world, p2p_variant=a.p2p_variant)
     # Secondary, clearly labelled measurement: the same iteration with the OTHER arithmetic of the MLP GEMMs.
     alt = None
-    main_gemm = agent.policy.gemm
-    other = "f32" if main_gemm == "bf16x3" else "bf16x3"
+    main_gemm = "f16x2" if agent.policy.h2_live() else agent.policy.gemm
+    h2_overflows = int(agent.policy.h2_overflows)
+    others = {"f16x2": ["f32", "bf16x3"], "bf16x3": ["f32"], "f32": ["bf16x3"]}[main_gemm]
+    alts = []
     if not a.no_alt_gemm:
-        try:        # the secondary figure must never cost the primary one
-            agent.policy.gemm = other
-            iteration()
-            fence()
-            a0 = time.perf_counter()
-            for _ in range(2):
+        for other in others:
+            try:        # the secondary figures must never cost the primary one
+                agent.policy.gemm = other
                 iteration()
-            fence()
-            alt_s = time.perf_counter() - a0
-            if world > 1:
-                tt = torch.tensor([alt_s], device=dev, dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                alt_s = float(tt[0])
-            alt = {"gemm": other, "arithmetic": GEMM_LABEL[other],
-                   "value": round(world * a.num_envs * T * 2 / alt_s, 1), "unit": "env-steps/s", "steps": 2,
-                   "ms_per_step": round(alt_s / 2 * 1e3, 3), "update_path": agent.policy.update_path()}
-        except Exception as e:      # noqa: BLE001
-            alt = {"gemm": other, "error": repr(e)[:200]}
-        finally:
-            agent.policy.gemm = main_gemm
+                fence()
+                a0 = time.perf_counter()
+                for _ in range(2):
+                    iteration()
+                fence()
+                alt_s = time.perf_counter() - a0
+                if world > 1:
+                    tt = torch.tensor([alt_s], device=dev, dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    alt_s = float(tt[0])
+                alts.append({"gemm": other, "arithmetic": GEMM_LABEL[other],
+                             "value": round(world * a.num_envs * T * 2 / alt_s, 1), "unit": "env-steps/s", "steps": 2,
+                             "ms_per_step": round(alt_s / 2 * 1e3, 3), "update_path": agent.policy.update_path()})
+            except Exception as e:      # noqa: BLE001
+                alts.append({"gemm": other, "error": repr(e)[:200]})
+            finally:
+                agent.policy.gemm = main_gemm
+        alt = alts[0] if alts else None
     finite = all(torch.isfinite(p).all().item() for p in agent.net.parameters())
     backend = dist.get_backend() if world > 1 else None
     agent_exchange = {"p2p": "one-shot peer-to-peer kernel over hipIpc windows (dp_allreduce_p2p)",
@@ -923,7 +997,8 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if main_gemm == "f32" else "f32 (bf16x3 operand split, fp32 accumulate)",
+            "dtype": {"f32": "f32", "bf16x3": "f32 (bf16x3 operand split, fp32 accumulate)",
+                      "f16x2": "f32 (optimizer step: fp16x2 operand split; rollout policy + critic: bf16x3 operand split; fp32 accumulate)"}[main_gemm],
             "data": "synthetic",
             "config": {"workload": "fly_ppo_iteration_%denvs_T%d" % (a.num_envs, T),
                        "num_envs_per_gpu": a.num_envs, "rollout_size": T, "optimizer_steps_per_iteration": 75,
@@ -939,6 +1014,7 @@ def main():
                 None if not persist_s else round(world * a.num_envs * T / persist_s, 1),
             "params_finite": finite,
             "refused_steps": refused,                  # fused forward+backward launches whose optimizer steps were refused and redone
+            "h2_overflow_updates": h2_overflows,       # updates in which an fp16x2 step did not fit fp16 and the rest was redone in bf16x3
             "mean_episode_return": None if ep_cnt == 0 else round(ep_ret, 4),
             "mean_episode_length": None if ep_cnt == 0 else round(ep_len, 2), "episodes_finished": ep_cnt,
         }
@@ -947,13 +1023,15 @@ def main():
             line["grad_exchange_variants_us"] = exchange_us         # rank 0, HIP events, the exchange alone
             line["p2p_selftest"] = p2p_selftest
         if alt:
-            line["alt_gemm"] = alt
+            line["alt_gemm"] = alt                   # strict fp32 (v_mfma_f32_32x32x2_f32) when `value` is f16x2 / bf16x3
+        if len(alts) > 1:
+            line["alt_gemm_2"] = alts[1]             # f16x2 runs: bf16x3 for every GEMM (round 4's default), same box
         ks = kernel_rooflines(a.num_envs, T, a.kernel_reps, main_gemm)
         line["roofline"] = ks[0]                     # the dominant kernel of one iteration
         line["kernels"] = ks[1:]
         if world == 1 and not a.no_dqn:
-            try:        # BASELINE configs[4], short and labelled: 32768 envs, stated ring, 3 timed env steps with one update each
-                d = dqn_measure(a.dqn_envs, a.dqn_mini_batch, 1, 3, max(5, a.kernel_reps // 4))
+            try:        # BASELINE configs[4], short and labelled: 32768 envs, stated ring, 10 timed env steps (after 2) with one update each
+                d = dqn_measure(a.dqn_envs, a.dqn_mini_batch, 2, 10, max(5, a.kernel_reps // 4))
                 line["dqn"] = {k: d[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config",
                                                  "params_finite", "roofline")}
             except Exception as e:      # noqa: BLE001

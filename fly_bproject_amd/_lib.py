@@ -19,6 +19,7 @@ class FlyBuffers(C.Structure):
                                           "done_return", "done_length", "done_count")]
 
 
+ABI_VERSION = 10        # include/flyhip.h as this package binds it (fly_abi_version(): argument lists changed between versions)
 # name -> argtypes; every entry point returns int except fly_last_error
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SYMBOLS = {
@@ -47,7 +48,9 @@ SYMBOLS = {
     "mlp_grad_w": [_P] * 8 + [_L, _P, _P, _P, _P, _P, _P, _I, _P],
     "mlp_fused_workspace_floats": [],
     "mlp_fused_grad": [_P] * 3 + [_P, _L] + [_P] * 5 + [_F, _F] + [_P] * 6 + [C.POINTER(_P), _P],
-    "mlp_adam_step": [_P] * 10 + [_F, _F, _F, _F, _F, _F, _P, _I, _P, _P, _P, _P, _P, _P, _P],
+    "mlp_fused_h2_workspace_floats": [],
+    "mlp_fused_grad_h2": [_P] * 5 + [_I, _P, _L] + [_P] * 5 + [_F, _F] + [_P] * 6 + [C.POINTER(_P), _P],
+    "mlp_adam_step": [_P] * 10 + [_F, _F, _F, _F, _F, _F, _P, _I, _P, _P, _P, _P, _P, _P] + [_P] * 4 + [_P],
     "dqn_eps_greedy": [_P, _P, _P, _F, _I, _P, _L, _P],
     "dqn_huber_td": [_P, _P, _P, _P, _P, _F, _I, _L, _P, _P, _P],
     "dqn_forward": [_P, _P, _P, _L, _P, _P],
@@ -92,6 +95,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
         fn.argtypes = argtypes
         fn.restype = C.c_int64 if name.endswith(("_workspace_floats", "_image_halves")) else C.c_int
+    if lib.fly_abi_version() != ABI_VERSION:
+        raise FlyHipError("stale libflyhip.so (ABI %d, this package was written for %d): rebuild it "
+                          "(`make -C fly_bproject_amd/csrc`)" % (lib.fly_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

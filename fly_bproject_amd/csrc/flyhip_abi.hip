@@ -63,7 +63,15 @@ extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PF, float* PT, con
                                              float* v, int* step, float lr, float beta1, float beta2, float eps,
                                              float max_norm, float grad_scale, float* norm_ws, int norm_ready,
                                              uint16_t* PB, uint16_t* PTB, const int* idx_fb, const int* idx_tb,
-                                             int* step_out, const int* grad_invalid, void* stream);
+                                             int* step_out, const int* grad_invalid, uint16_t* PH, uint16_t* PTH,
+                                             float* h2_scales, float* h2_wmax, void* stream);
+extern "C" int64_t flyhip_mlp_fused_h2_workspace_floats(void);
+extern "C" hipError_t flyhip_launch_mlp_fused_grad_h2(const float* P, const uint16_t* PH, const uint16_t* PTH, float* fsc, int* ovf,
+                                                      int freeze, const float* x, int64_t n, const float* action,
+                                                      const float* old_logp, const float* adv, const float* target, const float* var,
+                                                      float inv_batch, float clip, float* workspace, float* grad_out,
+                                                      const float* norm_mask, float* norm_ws, int* norm_step, float* loss_part,
+                                                      float* const* dump, void* stream);
 
 extern "C" hipError_t flyhip_launch_bookkeeping(const float* reward, int64_t n, float* score_acc, float score_scale,
                                                 float* action_var, int nvar, float var_decay, float var_min,
@@ -165,7 +173,7 @@ int launch(FlyHandle h, int phases, const float* actions, const FlyBuffers* b, v
 extern "C" {
 
 const char* fly_last_error(void) { return g_err; }
-int fly_abi_version(void) { return 9; }
+int fly_abi_version(void) { return 10; }
 
 int fly_create(const FlyConfig* cfg, FlyHandle* out)
 {
@@ -454,21 +462,52 @@ int mlp_fused_grad(const float* params, const uint16_t* params_b3, const uint16_
     return FLY_OK;
 }
 
+int64_t mlp_fused_h2_workspace_floats(void) { return flyhip_mlp_fused_h2_workspace_floats(); }
+
+int mlp_fused_grad_h2(const float* params, const uint16_t* params_h2, const uint16_t* params_t_h2, float* h2_scales,
+                      int32_t* h2_overflow, int32_t freeze, const float* x, int64_t n, const float* action,
+                      const float* old_logp, const float* adv, const float* target, const float* var, float inv_batch,
+                      float clip, float* workspace, float* grad, const float* norm_mask, float* norm_ws, int32_t* norm_step,
+                      float* loss_part, float* const* debug_dump, void* stream)
+{
+    if ((norm_ws != nullptr) != (norm_mask != nullptr) || (norm_ws != nullptr) != (norm_step != nullptr))
+        return fail(FLY_E_ARG, "mlp_fused_grad_h2: norm_mask, norm_ws and norm_step go together");
+    if (!params || !params_h2 || !params_t_h2 || !h2_scales || !h2_overflow)
+        return fail(FLY_E_ARG, "mlp_fused_grad_h2: needs params, both fp16x2 plane buffers, the scale table and the overflow word");
+    if (!x || !action || !old_logp || !adv || !target || !var || !workspace || !grad)
+        return fail(FLY_E_ARG, "mlp_fused_grad_h2: null pointer");
+    if (n <= 0) return fail(FLY_E_ARG, "mlp_fused_grad_h2: n must be > 0");
+    if (debug_dump) {
+        if (!debug_dump[0]) return fail(FLY_E_ARG, "mlp_fused_grad_h2: debug_dump[0] is null");
+        if (debug_dump[1])
+            for (int i = 2; i < 8; ++i)
+                if (!debug_dump[i]) return fail(FLY_E_ARG, "mlp_fused_grad_h2: debug_dump[%d] is null", i);
+    }
+    hipError_t e = flyhip_launch_mlp_fused_grad_h2(params, params_h2, params_t_h2, h2_scales, h2_overflow, freeze, x, n, action, old_logp,
+                                                   adv, target, var, inv_batch, clip, workspace, grad, norm_mask, norm_ws, norm_step,
+                                                   loss_part, debug_dump, stream);
+    if (e != hipSuccess) return hip_fail(e, "mlp_fused_grad_h2 launch");
+    return FLY_OK;
+}
+
 int mlp_adam_step(float* params, float* params_frag, float* params_t_frag, const int32_t* idx_frag,
                   const int32_t* idx_t_frag, const float* grad, const float* mask, float* exp_avg,
                   float* exp_avg_sq, int32_t* step, float lr, float beta1, float beta2, float eps,
                   float max_norm, float grad_scale, float* norm_ws, int32_t norm_ready, uint16_t* params_b3,
                   uint16_t* params_t_b3, const int32_t* idx_b3, const int32_t* idx_t_b3, int32_t* step_out,
-                  const int32_t* grad_invalid, void* stream)
+                  const int32_t* grad_invalid, uint16_t* params_h2, uint16_t* params_t_h2, float* h2_scales, float* h2_wmax,
+                  void* stream)
 {
     if (params_b3 && (!params_t_b3 || !idx_b3 || !idx_t_b3))
         return fail(FLY_E_ARG, "mlp_adam_step: params_b3 needs params_t_b3, idx_b3 and idx_t_b3");
+    if (params_h2 && (!params_t_h2 || !h2_scales || !h2_wmax || !params_b3))
+        return fail(FLY_E_ARG, "mlp_adam_step: params_h2 needs params_t_h2, h2_scales, h2_wmax and the bf16x3 planes with their index maps");
     if (!params || !params_frag || !params_t_frag || !idx_frag || !idx_t_frag || !grad || !mask || !exp_avg ||
         !exp_avg_sq || !step || !norm_ws)
         return fail(FLY_E_ARG, "mlp_adam_step: null pointer");
     hipError_t e = flyhip_launch_mlp_adam(params, params_frag, params_t_frag, idx_frag, idx_t_frag, grad, mask, exp_avg, exp_avg_sq, step, lr, beta1, beta2,
                                           eps, max_norm, grad_scale, norm_ws, norm_ready, params_b3, params_t_b3, idx_b3, idx_t_b3,
-                                          step_out, grad_invalid, stream);
+                                          step_out, grad_invalid, params_h2, params_t_h2, h2_scales, h2_wmax, stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_adam_step launch");
     return FLY_OK;
 }

@@ -31,6 +31,7 @@
 namespace {
 
 #include "mlp_gemm.inc"
+#include "fs_stamp.inc"
 #include "mlp_forward.inc"
 #include "mlp_backward.inc"
 #include "mlp_grad_w.inc"
@@ -480,6 +481,7 @@ extern "C" int flyhip_mlp_reduce_blocks(void) { return RED_BLOCKS; }
 // ---- the fused optimizer-step gradient: mlp_fused_step_kernel + the fixed-order reduction of its per-workgroup slabs ------
 static int g_fused_grid_override = 0;    // test / tuning hook: fewer workgroups than CUs (each then walks more tiles)
 extern "C" void flyhip_debug_set_fused_grid(int grid) { g_fused_grid_override = grid; }
+extern "C" int flyhip_debug_get_fused_grid(void) { return g_fused_grid_override; }
 static int fused_cus()
 {
     static int cus = 0;
@@ -555,7 +557,8 @@ extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PF, float* PT, con
                                              float* v, int* step, float lr, float beta1, float beta2, float eps,
                                              float max_norm, float grad_scale, float* norm_ws, int norm_ready,
                                              uint16_t* PB, uint16_t* PTB, const int* idx_fb, const int* idx_tb,
-                                             int* step_out, const int* grad_invalid, void* stream)
+                                             int* step_out, const int* grad_invalid, uint16_t* PH, uint16_t* PTH,
+                                             float* h2_scales, float* h2_wmax, void* stream)
 {
     int nparts = ADAM_BLOCKS;
     float part_scale = 1.0f;
@@ -572,6 +575,6 @@ extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PF, float* PT, con
     }
     hipLaunchKernelGGL(mlp_adam_apply_kernel, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, P, PF, PT,
                        idx_f, idx_t, G, mask, m, v, step, lr, beta1, beta2, eps, max_norm, grad_scale, norm_ws, nparts,
-                       part_scale, PB, PTB, idx_fb, idx_tb, step_out, grad_invalid);
+                       part_scale, PB, PTB, idx_fb, idx_tb, step_out, grad_invalid, PH, PTH, h2_scales, h2_wmax);
     return hipGetLastError();
 }

@@ -100,6 +100,27 @@ def build_plane_maps():
     return idx_fb, idx_tb
 
 
+# fp16x2 planes of the fused optimizer step (csrc/mlp_fused_h2.inc): PB's / PTB's layout with two terms per k block
+PH_HALVES, PTH_HALVES = PB_HALVES * 2 // 3, PTB_HALVES * 2 // 3
+H2_SCALE_FLOATS, H2_INV, H2_W0, ADAM_BLOCKS = 48, 16, 8, 73
+H2_CLASSES = ("x", "h1", "h2", "h3", "dz4", "dz3", "dz2", "dz1")
+
+
+def split_f16x2(w, scale):
+    """fp32 tensor -> two int16 tensors holding the fp16 terms h0 + h1 ~= w * scale (|error| <= 2^-23 |w scale|)."""
+    y = w * scale
+    h0 = y.to(torch.float16)
+    h1 = (y - h0.float()).to(torch.float16)
+    return [t.view(torch.int16) for t in (h0, h1)]
+
+
+def h2_weight_scale(wmax):
+    """The power of two mlp_adam_step gives a layer whose largest |w| was `wmax`: the maximum lands in [2^11, 2^12)."""
+    import math
+    m = min(max(float(wmax), 2.0 ** -7), 2.0 ** 60)
+    return 2.0 ** (11 - math.floor(math.log2(m)))
+
+
 def untile(t, n, N):
     """[rows][N] view of a saved activation / dZ buffer, which the kernels keep in tile-fragment order
     (csrc/mlp_mfma.hip, frag_off): per 32-row tile and 32-column tile a block of 1024 floats
@@ -130,11 +151,29 @@ class PackedPolicy:
         # GEMM arithmetic of the MFMA kernels: "bf16x3" (default) = three-term bf16 split of both fp32 operands on
         # v_mfma_f32_32x32x16_bf16, fp32 accumulate (held to the reference's golden vectors at the fp32 tolerances and to fp64:
         # tests/test_ppo_gpu.py, tests/test_mlp_train_gpu.py, csrc/mlp_layout.h); "f32" = v_mfma_f32_32x32x2_f32 (FLY_GEMM=f32)
-        self._gemm = os.environ.get("FLY_GEMM", "bf16x3")
+        env_gemm = os.environ.get("FLY_GEMM")               # names EVERY GEMM when given ("f16x2": bf16x3 + the fp16x2 optimizer step)
+        self._gemm = "bf16x3" if env_gemm in (None, "f16x2") else env_gemm
         self.gemm_infer = os.environ.get("FLY_GEMM_INFER", self._gemm)
         assert self._gemm in ("f32", "bf16x3") and self.gemm_infer in ("f32", "bf16x3")
         self.PB = torch.zeros(PB_HALVES, dtype=torch.int16, device=self.device)
         self.PTB = torch.zeros(PTB_HALVES, dtype=torch.int16, device=self.device)
+        # Arithmetic of the fused optimizer-step gradient (only): "bf16x3" (mlp_fused_grad) or "f16x2" (mlp_fused_grad_h2: two fp16 terms
+        # per operand, three products per k block, per-class power-of-two scales; csrc/mlp_fused_h2.inc).  The rollout's policy, the
+        # critic pass and every fallback stay on `gemm`.  FLY_STEP_GEMM / --step_gemm / policy.step_gemm = ...
+        # DEFAULT (round 5): f16x2, with bf16x3 as the A/B and as the fallback of a refused step; `policy.gemm = "bf16x3"` (or
+        # FLY_GEMM=bf16x3) names every GEMM, the step included.
+        self._step_gemm = os.environ.get("FLY_STEP_GEMM", "f16x2" if env_gemm in (None, "f16x2") else "bf16x3")
+        assert self._step_gemm in ("bf16x3", "f16x2")
+        self.PH = torch.zeros(PH_HALVES, dtype=torch.int16, device=self.device)
+        self.PTH = torch.zeros(PTH_HALVES, dtype=torch.int16, device=self.device)
+        self.h2_scales = torch.zeros(H2_SCALE_FLOATS, dtype=torch.float32, device=self.device)
+        self.h2_wmax = torch.zeros(2 * ADAM_BLOCKS * 4, dtype=torch.float32, device=self.device)
+        self.h2_overflow = torch.zeros(1, dtype=torch.int32, device=self.device)     # sticky: a launch's values did not fit fp16
+        self.h2_freeze = False              # tests: the reduction leaves the scale table alone
+        self.h2_calibrated = False
+        self.h2_suspended = False           # True while refused steps are redone on the bf16x3 kernel (the planes stay maintained)
+        self.h2_overflows = 0               # updates in which the fp16x2 step was refused and redone on bf16x3
+        self._h2_reset_scales()
         idx_fb, idx_tb = build_plane_maps()
         self.idx_fb = torch.from_numpy(idx_fb).to(self.device)
         self.idx_tb = torch.from_numpy(idx_tb).to(self.device)
@@ -198,8 +237,57 @@ class PackedPolicy:
                 for term, plane in enumerate(split_bf16x3(self.P[src])):
                     dst_buf[dst + 512 * term] = plane
 
+        if self.h2_live():
+            self._refresh_planes_h2()
+
+    def h2_live(self):
+        return self._step_gemm == "f16x2" and self._gemm == "bf16x3"
+
+    def _h2_reset_scales(self):
+        """Starting scales of the activation / gradient classes (calibrate_h2 replaces them by measured ones)."""
+        s = torch.ones(H2_SCALE_FLOATS)
+        s[:4] = 2.0 ** 4                    # x, h1 .. h3: O(1 .. 100)
+        s[4:8] = 2.0 ** 28                  # dz4 .. dz1: O(1e-6)
+        s[H2_INV:H2_INV + 16] = 1.0 / s[:16]
+        s[32:] = 0.0
+        self.h2_scales.copy_(s)
+        self.h2_calibrated = False
+
+    def _refresh_planes_h2(self):
+        """fp16x2 weight planes and their per-layer scales from the master weights (what mlp_adam_step maintains step by step)."""
+        with torch.no_grad():
+            bounds = (OFF_W1, OFF_W2, OFF_W3, OFF_W4, PACKED)
+            wmax = torch.zeros(2, ADAM_BLOCKS, 4)
+            sc = self.h2_scales.cpu()
+            layer_scale = torch.ones(PACKED, device=self.device)
+            for l in range(4):
+                sel = self._src_fb[(self._src_fb >= bounds[l]) & (self._src_fb < bounds[l + 1])]
+                m = float(self.P[sel].abs().max())
+                wmax[:, 0, l] = m                               # both parities: whichever step comes next finds it
+                k = h2_weight_scale(m)
+                sc[H2_W0 + l], sc[H2_INV + H2_W0 + l] = k, 1.0 / k
+                layer_scale[bounds[l]:bounds[l + 1]] = k
+            self.h2_wmax.copy_(wmax.reshape(-1))
+            self.h2_scales.copy_(sc)
+            for dst_buf, src, dst in ((self.PH, self._src_fb, self._dst_fb), (self.PTH, self._src_tb, self._dst_tb)):
+                dh = (dst // 1536) * 1024 + dst % 1536
+                for term, plane in enumerate(split_f16x2(self.P[src], layer_scale[src])):
+                    dst_buf[dh + 512 * term] = plane
+
     def _planes_live(self):
         return self._gemm == "bf16x3" or self.gemm_infer == "bf16x3"
+
+    @property
+    def step_gemm(self):
+        return self._step_gemm if self._gemm == "bf16x3" else self._gemm
+
+    @step_gemm.setter
+    def step_gemm(self, mode):
+        assert mode in ("bf16x3", "f16x2")
+        was = self.h2_live()
+        self._step_gemm = mode
+        if self.h2_live() and not was:
+            self._refresh_planes_h2()
 
     @property
     def gemm(self):
@@ -210,12 +298,19 @@ class PackedPolicy:
         """Arithmetic of EVERY MLP GEMM of this policy: the update's forward, dX chain and dW, the rollout's
         policy launch and the critic pass.  Switching to bf16x3 rebuilds the term planes: the Adam kernel only
         maintains them while a bf16x3 mode is active (six extra scattered stores per weight otherwise wasted)."""
+        if mode == "f16x2":                 # bf16x3 everywhere, the fused optimizer step in fp16x2 (the default configuration)
+            self.gemm = "bf16x3"
+            self.step_gemm = "f16x2"
+            return
         assert mode in ("f32", "bf16x3")
-        was_live = self._planes_live()
+        was_live, was_h2 = self._planes_live(), self.h2_live()
         self._gemm = mode
         self.gemm_infer = mode
+        self._step_gemm = "bf16x3"          # an explicit arithmetic names every GEMM, the optimizer step included
         if self._planes_live() and not was_live:
             self._refresh_planes()
+        elif self.h2_live() and not was_h2:
+            self._refresh_planes_h2()
     version = 0         # bumped whenever the weights change: consumers of cached network outputs compare it
 
     def _plane_args(self):
@@ -223,6 +318,12 @@ class PackedPolicy:
             return (None, None, None, None)
         p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
         return (p(self.PB), p(self.PTB), p(self.idx_fb), p(self.idx_tb))
+
+    def _h2_args(self):
+        if not self.h2_live():
+            return (None, None, None, None)
+        p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+        return (p(self.PH), p(self.PTH), p(self.h2_scales), p(self.h2_wmax))
 
     def pb_ptr(self):
         """Term planes for the UPDATE's forward (minibatch_grad); inference launches (rollout policy,
@@ -303,10 +404,11 @@ class PackedPolicy:
 
     def update_can_be_refused(self):
         """True when a launch of the current update path can leave an invalid gradient that the optimizer kernels then refuse on
-        the device (the fused forward+backward launch's tile hand-off): the caller must read the step counter after the update
-        and redo what was refused.  The fused optimizer step (`mlp_fused_grad`) and the two-launch path cannot."""
+        the device (the fused forward+backward launch's tile hand-off; a value of the fp16x2 step that did not fit fp16): the caller
+        must read the step counter after the update and redo what was refused.  The bf16x3 fused optimizer step (`mlp_fused_grad`)
+        and the two-launch path cannot."""
         if self.fused_step and self.gemm == "bf16x3":
-            return False
+            return self.h2_live()
         return bool(self.fuse_fwd_bwd)
 
     def check_fused_launch(self):
@@ -368,19 +470,52 @@ class PackedPolicy:
         n = x.shape[0]
         p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
         if self._fused_ws is None:
-            self._fused_ws = torch.empty(int(self._lib.mlp_fused_workspace_floats()), device=self.device)
+            self._fused_ws = torch.empty(int(max(self._lib.mlp_fused_workspace_floats(), self._lib.mlp_fused_h2_workspace_floats())),
+                                         device=self.device)
         nm = (p(self.grad_mask), p(self._norm_ws), p(self.step)) if fuse_norm else (None, None, None)
         dptr = None
         if dump:
             s, d = self.saves, self.dz
             arr = (C.c_void_p * 8)(*[t.data_ptr() for t in (s["out"], s["h1"], s["h2"], s["h3"], d["dz4"], d["dz3"], d["dz2"], d["dz1"])])
             dptr = arr
+        if self.h2_live() and not self.h2_suspended:
+            _lib.check(self._lib.mlp_fused_grad_h2(p(self.P), p(self.PH), p(self.PTH), p(self.h2_scales), p(self.h2_overflow),
+                                                   C.c_int(1 if self.h2_freeze else 0), p(x), C.c_int64(n), p(action), p(old_logp),
+                                                   p(adv), p(target), p(var), C.c_float(inv_b), C.c_float(clip), p(self._fused_ws),
+                                                   p(self.G), *nm, p(self.loss_part), dptr, _lib.stream_ptr()), "mlp_fused_grad_h2")
+            return
         _lib.check(self._lib.mlp_fused_grad(p(self.P), p(self.PB), p(self.PTB), p(x), C.c_int64(n), p(action), p(old_logp), p(adv),
                                             p(target), p(var), C.c_float(inv_b), C.c_float(clip), p(self._fused_ws), p(self.G), *nm,
                                             p(self.loss_part), dptr, _lib.stream_ptr()), "mlp_fused_grad")
 
+    def calibrate_h2(self, x, action, old_logp, adv, target, var, clip, global_rows=None, max_launches=12):
+        """Bring the activation / gradient scales of the fp16x2 step to the data (host-synchronising; before the first update on a new
+        network or after an overflow): launch the gradient on one minibatch -- the result is discarded, the step counter untouched --
+        until a launch fits fp16 and leaves the scales it found.  Every launch sets each class's scale from the maximum it saw, and an
+        overflowing class garbles only what lies downstream of it, so the table settles in at most one launch per class.  Returns
+        the number of launches."""
+        assert self.h2_live()
+        frozen, self.h2_freeze = self.h2_freeze, False
+        try:
+            for k in range(1, max_launches + 1):
+                self.h2_overflow.zero_()
+                before = self.h2_scales[:8].clone()
+                self.minibatch_grad(x, action, old_logp, adv, target, var, clip, global_rows=global_rows, fuse_norm=False)
+                fit = int(self.h2_overflow.item()) == 0
+                if fit and torch.equal(before, self.h2_scales[:8]):
+                    self.h2_calibrated = True
+                    return k
+            raise _lib.FlyHipError("calibrate_h2: the fp16x2 scales did not settle in %d launches (maxima %s)"
+                                   % (max_launches, self.h2_scales[32:40].tolist()))
+        finally:
+            self.h2_overflow.zero_()
+            self.h2_freeze = frozen
+
     def update_path(self):
         """Which launches one optimizer step is made of (for the bench line)."""
+        if self.fused_step and self.h2_live():
+            return ("mlp_fused_grad_h2 (ONE persistent launch: forward + loss + dX chain + dW per tile in fp16x2, slabs reduced, scales "
+                    "tracked) + mlp_adam_step, gemm=bf16x3, step_gemm=f16x2")
         if self.fused_step and self.gemm == "bf16x3":
             return "mlp_fused_grad (ONE persistent launch: forward + loss + dX chain + dW per tile, slabs reduced) + mlp_adam_step, gemm=bf16x3"
         if self.fuse_fwd_bwd:
@@ -417,5 +552,5 @@ class PackedPolicy:
                                            C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
                                            C.c_float(self.max_norm), C.c_float(grad_scale), p(self._norm_ws),
                                            C.c_int(1 if norm_ready else 0), *self._plane_args(), step_out,
-                                           p(grad_invalid) if grad_invalid is not None else None, _lib.stream_ptr()),
+                                           p(grad_invalid) if grad_invalid is not None else None, *self._h2_args(), _lib.stream_ptr()),
                    "mlp_adam_step")

@@ -353,6 +353,12 @@ class PPO:
                               self_norm=sync_grads, grad_invalid=self._p2p.err if (sync_grads and self._p2p is not None) else None)
 
         self._check_step_counter()       # the previous update's counter, copied while this rollout ran
+        if pol.h2_live() and pol.fused_step and not pol.h2_calibrated:
+            # fp16x2 step: the per-class scales are measured on the first minibatch before anything depends on them (a new
+            # network, or an update whose values outgrew the scales: a few discarded launches, host-synchronising, rare)
+            k, j = slices[0]
+            pol.calibrate_h2(obs[k:j].view(rows, self.num_obs), action[k:j].view(rows, self.num_acts), old_log_prob[k:j].view(rows),
+                             advantage[k:j].view(rows), target[k:j].view(rows), self._action_var, self.clip)
         run(slices)
         if self._p2p is not None and not self._p2p.check():
             # FIRST, before anything looks at the step counter: a bounded wait of the peer-to-peer exchange expired on this
@@ -387,21 +393,32 @@ class PPO:
         # So the device step counter says how many minibatches really happened: redo the rest through the
         # two-launch path -- bit for bit what an undisturbed update leaves.  (Only this path -- the tile
         # hand-off of mlp_forward_backward -- is ever redone.)
+        h2 = pol.h2_live() and pol.fused_step
         for attempt in range(3):
             short = pol.steps_issued - int(pol.step.item())
-            if pol.fuse_fwd_bwd or short:
+            if (pol.fuse_fwd_bwd and not h2) or short:
                 pol.check_fused_launch()
             if short == 0:
                 break
             if short < 0 or short > len(slices) or attempt == 2:
                 raise _lib.FlyHipError("update: device step counter is %d steps behind the %d issued" % (short, pol.steps_issued))
-            pol.fuse_fwd_bwd = False
             pol.steps_issued -= short
-            print("mlp_forward_backward: %d of %d optimizer steps were refused on the device (a backward workgroup "
-                  "could not get its tile); redoing them with two launches" % (short, len(slices)))
+            if h2 and not pol.h2_suspended:
+                # a value of some launch did not fit fp16 under the scales its predecessor left (mlp_fused_h2.inc): that step and
+                # every later one were refused on the device (the sticky word), on every rank.  Redo them, in order, on the bf16x3
+                # kernel -- bit for bit what an undisturbed bf16x3 step leaves -- and measure the scales afresh before the next update.
+                pol.h2_overflow.zero_()
+                pol.h2_suspended = True
+                pol.h2_calibrated = False
+                pol.h2_overflows += 1
+            else:
+                pol.fuse_fwd_bwd = False
+                print("mlp_forward_backward: %d of %d optimizer steps were refused on the device (a backward workgroup "
+                      "could not get its tile); redoing them with two launches" % (short, len(slices)))
             run(slices[len(slices) - short:])
             if self._p2p is not None and not self._p2p.check():
                 raise _lib.FlyHipError("dp_allreduce_p2p: a rank never published its gradient while refused steps were redone")
+        pol.h2_suspended = False
         self.optim_step += len(slices)
         self._drain_log(block=True)                     # the queue is drained anyway: pending log lines cost nothing here
         self._finish_update(sync_grads)

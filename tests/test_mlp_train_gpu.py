@@ -20,7 +20,9 @@ def _bare_agent(net, var):
     return p
 
 
-GEMMS = ["f32", "bf16x3"]     # both arithmetics are held to autograd and to the reference's g7 golden at the SAME tolerances
+# every arithmetic is held to autograd and to the reference's g7 golden at the SAME tolerances ("f16x2" = bf16x3 everywhere with the
+# fused optimizer-step gradient in the two-term fp16 arithmetic, csrc/mlp_fused_h2.inc)
+GEMMS = ["f32", "bf16x3", "f16x2"]
 
 
 def _setup(n, seed, sd=None, gemm=None):
@@ -44,6 +46,8 @@ def _setup(n, seed, sd=None, gemm=None):
         old_logp = diag_gauss_logprob(mu, action, var) + 0.3 * torch.randn(n, device=DEV, generator=g)
     adv = torch.randn(n, device=DEV, generator=g)
     target = torch.randn(n, device=DEV, generator=g) * 1.5
+    if gemm == "f16x2":             # the per-class scales of the fp16x2 step are measured on the data (PPO._update_hip does this too)
+        pol.calibrate_h2(x, action, old_logp, adv, target, var, 0.2)
     return net, ref, pol, (x, action, old_logp, adv, target, var)
 
 
@@ -118,6 +122,9 @@ def test_update_matches_reference_golden(golden, gemm):
     rows = mc * N
     steps = 0
     first = None
+    if gemm == "f16x2":
+        pol.calibrate_h2(obs[0:mc].reshape(rows, 73), acts[0:mc].reshape(rows, 18), logp[0:mc].reshape(rows), adv[0:mc].reshape(rows),
+                         target[0:mc].reshape(rows), var, 0.2)
     for _ in range(5):
         k = 0
         for j in range(mc, T, mc):
@@ -130,7 +137,7 @@ def test_update_matches_reference_golden(golden, gemm):
                 np.testing.assert_allclose(float(pol.grad_norm), float(g["gradnorm0"]), rtol=2e-4)
             steps += 1
             k = j
-    assert steps == 75
+    assert steps == 75 and int(pol.step) == 75 and int(pol.h2_overflow) == 0        # (no step of the fp16x2 run was refused)
     np.testing.assert_allclose(first[0], float(g["loss0"]), rtol=2e-5)
     coef = min(1.0, 1.0 / (float(g["gradnorm0"]) + 1e-6))      # g0_* were recorded after clip_grad_norm_ scaled them in place
     for name, view in pol.views.items():         # the reference's own gradients of the first minibatch (ppo.py:197-198)

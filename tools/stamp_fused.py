@@ -18,11 +18,16 @@ net = Net(73, 18).to("cuda:0")
 pol = PackedPolicy(net, "cuda:0")
 pol.init_training(rows)
 pol.gemm = "bf16x3"
+H2 = len(sys.argv) > 2 and sys.argv[2] == "f16x2"       # stamp_fused.py ROWS f16x2: the fp16x2 kernel (same stamp slots)
+if H2:
+    pol.step_gemm = "f16x2"
 x = torch.randn(rows, 73, device="cuda:0")
 act = torch.rand(rows, 18, device="cuda:0") * 2 - 1
 olp = torch.randn(rows, device="cuda:0") - 20
 adv = torch.randn(rows, device="cuda:0"); tgt = torch.randn(rows, device="cuda:0")
 var = torch.full((18,), 0.2, device="cuda:0")
+if H2:
+    pol.calibrate_h2(x, act, olp, adv, tgt, var, 0.2)
 for _ in range(30):
     pol.minibatch_grad(x, act, olp, adv, tgt, var, 0.2)
 torch.cuda.synchronize()
@@ -31,11 +36,16 @@ SLOTS = 32
 stamps = torch.zeros(grid * 64 * SLOTS, dtype=torch.int64, device="cuda:0")
 p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
 arr = (C.c_void_p * 8)(stamps.data_ptr(), None, None, None, None, None, None, None)
-ws = torch.empty(int(_lib.load().mlp_fused_workspace_floats()), device="cuda:0")
+ws = torch.empty(int(max(_lib.load().mlp_fused_workspace_floats(), _lib.load().mlp_fused_h2_workspace_floats())), device="cuda:0")
 for _ in range(3):
-    _lib.check(_lib.load().mlp_fused_grad(p(pol.P), p(pol.PB), p(pol.PTB), p(x), rows, p(act), p(olp), p(adv), p(tgt), p(var),
-                                          C.c_float(1.0 / rows), C.c_float(0.2), p(ws), p(pol.G), None, None, None, p(pol.loss_part),
-                                          arr, None), "stamp")
+    if H2:
+        _lib.check(_lib.load().mlp_fused_grad_h2(p(pol.P), p(pol.PH), p(pol.PTH), p(pol.h2_scales), p(pol.h2_overflow), 1, p(x), rows, p(act),
+                                                 p(olp), p(adv), p(tgt), p(var), C.c_float(1.0 / rows), C.c_float(0.2), p(ws), p(pol.G),
+                                                 None, None, None, p(pol.loss_part), arr, None), "stamp")
+    else:
+        _lib.check(_lib.load().mlp_fused_grad(p(pol.P), p(pol.PB), p(pol.PTB), p(x), rows, p(act), p(olp), p(adv), p(tgt), p(var),
+                                              C.c_float(1.0 / rows), C.c_float(0.2), p(ws), p(pol.G), None, None, None, p(pol.loss_part),
+                                              arr, None), "stamp")
 torch.cuda.synchronize()
 s = stamps.cpu().numpy().reshape(grid, 64, SLOTS).astype(np.int64)
 tiles = (rows + 31) // 32

@@ -21,9 +21,14 @@ act = torch.rand(rows, 18, device="cuda:0") * 2 - 1
 olp = torch.randn(rows, device="cuda:0") - 20
 adv = torch.randn(rows, device="cuda:0"); tgt = torch.randn(rows, device="cuda:0")
 var = torch.full((18,), 0.2, device="cuda:0")
-for gemm, fused in (("bf16x3", True), ("bf16x3", False), ("f32", False)):
+for gemm, fused in (("f16x2", True), ("bf16x3", True), ("f16x2", True), ("bf16x3", True), ("bf16x3", False), ("f32", False)):
     pol.gemm = gemm
+    pol.step_gemm = "f16x2" if gemm == "f16x2" else "bf16x3"
     pol.fused_step = fused
+    if gemm == "f16x2":
+        print("fp16x2 scales settled in %d launches" % pol.calibrate_h2(x, act, olp, adv, tgt, var, 0.2))
     t = _time_launches(lambda: pol.minibatch_grad(x, act, olp, adv, tgt, var, 0.2, fuse_norm=True), reps)
     t2 = _time_launches(lambda: (pol.minibatch_grad(x, act, olp, adv, tgt, var, 0.2, fuse_norm=True), pol.adam_step(norm_ready=True)), reps)
     print("%-7s fused_step=%-5s gradient %.1f us   gradient + adam %.1f us   (%s)" % (gemm, fused, t * 1e6, t2 * 1e6, pol.update_path()))
+    if gemm == "f16x2":
+        assert int(pol.h2_overflow) == 0

@@ -36,11 +36,13 @@ def parse_args(argv=None):
     parser.add_argument('--reward', type=str, default="standing", choices=["standing", "walking"])
     parser.add_argument('--max_steps', type=int, default=0, help='stop after this many env steps (0 = run until env.end)')
     parser.add_argument('--seed', type=int, default=0)
-    parser.add_argument('--gemm', type=str, default=None, choices=["f32", "bf16x3"],
-                        help='arithmetic of EVERY MLP GEMM (rollout policy, critic pass, the update): bf16x3 (default) = fp32 '
-                             'operands split exactly into three bf16 terms on the bf16 matrix pipe, fp32 accumulate (held to the '
-                             'reference goldens at the fp32 tolerances, DESIGN.md 3.4); f32 = v_mfma_f32_32x32x2_f32.  '
-                             'Default: $FLY_GEMM or bf16x3')
+    parser.add_argument('--gemm', type=str, default=None, choices=["f32", "bf16x3", "f16x2"],
+                        help='arithmetic of the MLP GEMMs: f16x2 (default) = bf16x3 for the rollout policy and the critic pass, the '
+                             'optimizer-step gradient in the two-term fp16 split with three product terms and per-class '
+                             'power-of-two scales (DESIGN.md 3.4c; a step whose values do not fit fp16 is refused on the device '
+                             'and redone in bf16x3); bf16x3 = fp32 operands split exactly into three bf16 terms on the bf16 matrix '
+                             'pipe, fp32 accumulate, for EVERY GEMM (DESIGN.md 3.4); f32 = v_mfma_f32_32x32x2_f32.  All are held to '
+                             'the reference goldens at the fp32 tolerances.  Default: $FLY_GEMM or f16x2')
     parser.add_argument('--log_throughput', action='store_true',
                         help='append env-steps/s (all ranks, host clock, since the previous score line) to the score line '
                              '(ppo.py:257-260 prints the score only; off by default so that stdout stays the reference\'s)')
