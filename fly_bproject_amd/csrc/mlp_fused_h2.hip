@@ -33,7 +33,8 @@ static int h2_cus()
 static int64_t h2_slab_floats() { return fs_pad256(FS_STRIDE1) + fs_pad256(FS_STRIDE2) + fs_pad256(FS_STRIDE3) + fs_pad256(FS_STRIDE4); }
 
 // one partial slab per workgroup (chunked layout) + eight class maxima per workgroup behind them
-extern "C" int64_t flyhip_mlp_fused_h2_workspace_floats(void) { return (int64_t)h2_cus() * (h2_slab_floats() + H2_NACT_CLASSES); }
+// (+ 8 floats: the launch's unscale factors, left by workgroup 0 for the reduction)
+extern "C" int64_t flyhip_mlp_fused_h2_workspace_floats(void) { return (int64_t)h2_cus() * (h2_slab_floats() + H2_NACT_CLASSES) + 8; }
 
 extern "C" hipError_t flyhip_launch_mlp_fused_grad_h2(const float* P, const uint16_t* PH, const uint16_t* PTH, float* fsc, int* ovf,
                                                       int freeze, const float* x, int64_t n, const float* action,

@@ -102,7 +102,7 @@ def build_plane_maps():
 
 # fp16x2 planes of the fused optimizer step (csrc/mlp_fused_h2.inc): PB's / PTB's layout with two terms per k block
 PH_HALVES, PTH_HALVES = PB_HALVES * 2 // 3, PTB_HALVES * 2 // 3
-H2_SCALE_FLOATS, H2_INV, H2_W0, ADAM_BLOCKS = 48, 16, 8, 73
+H2_SCALE_FLOATS, H2_INV, H2_W0, ADAM_BLOCKS = 48, 16, 8, 291
 H2_CLASSES = ("x", "h1", "h2", "h3", "dz4", "dz3", "dz2", "dz1")
 
 
@@ -399,7 +399,11 @@ class PackedPolicy:
         differently: err 2) the two-launch path is used from the start -- same results."""
         n = min(self.max_rows, 64 * 32)
         z = lambda *shape: torch.zeros(*shape, device=self.device)   # noqa: E731
-        self.minibatch_grad(z(n, IN), z(n, NACT), z(n), z(n), z(n), torch.full((NACT,), 0.2, device=self.device), 0.2)
+        was, self.h2_suspended = self.h2_suspended, True        # (not a launch whose values the fp16x2 scales should be judged on)
+        try:
+            self.minibatch_grad(z(n, IN), z(n, NACT), z(n), z(n), z(n), torch.full((NACT,), 0.2, device=self.device), 0.2)
+        finally:
+            self.h2_suspended = was
         self.check_fused_launch()
 
     def update_can_be_refused(self):
@@ -408,7 +412,7 @@ class PackedPolicy:
         must read the step counter after the update and redo what was refused.  The bf16x3 fused optimizer step (`mlp_fused_grad`)
         and the two-launch path cannot."""
         if self.fused_step and self.gemm == "bf16x3":
-            return self.h2_live()
+            return self.h2_live() and os.environ.get("FLY_H2_DIAG_NO_STEP_READ") != "1"     # (diagnostic: what the blocking read costs)
         return bool(self.fuse_fwd_bwd)
 
     def check_fused_launch(self):

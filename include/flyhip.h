@@ -389,7 +389,7 @@ int mlp_adam_step(float* params, float* params_frag, float* params_t_frag, const
  *                 every launch marks its gradient invalid (grad[76] = 1, as mlp_grad_w does with a nonzero `err`) and does not
  *                 advance *norm_step, so mlp_adam_step refuses the step: the caller reads the step counter at the end of the
  *                 update, clears the word and redoes the refused steps, in order, with mlp_fused_grad;
- *   h2_wmax       (mlp_adam_step) device float [2][73][4]: per optimizer block and layer max |w|, double-buffered by step parity;
+ *   h2_wmax       (mlp_adam_step) device float [2][291][4]: per optimizer block and layer max |w|, double-buffered by step parity;
  *                 the scale of layer l's planes is taken from the previous step's maximum with 16x of headroom.
  * `workspace` holds mlp_fused_h2_workspace_floats() floats.  A first launch on a new network should be preceded by a few launches
  * whose result is discarded (scales converge in one launch per class that overflowed; fly_bproject_amd/policy.py: calibrate_h2).
@@ -397,7 +397,7 @@ int mlp_adam_step(float* params, float* params_frag, float* params_t_frag, const
 #define MLP_PH_HALVES_ABI 147456
 #define MLP_PTH_HALVES_ABI 106496
 #define MLP_H2_SCALE_FLOATS_ABI 48
-#define MLP_H2_WMAX_FLOATS_ABI 584
+#define MLP_H2_WMAX_FLOATS_ABI 2328
 int64_t mlp_fused_h2_workspace_floats(void);
 int mlp_fused_grad_h2(const float* params, const uint16_t* params_h2, const uint16_t* params_t_h2, float* h2_scales,
                       int32_t* h2_overflow, int32_t freeze, const float* x, int64_t n, const float* action,

@@ -34,9 +34,13 @@ olp = torch.randn(rows, device="cuda:0") - 20
 adv = torch.randn(rows, device="cuda:0")
 tgt = torch.randn(rows, device="cuda:0")
 var = torch.full((18,), 0.2, device="cuda:0")
+if pol.h2_live():          # the default optimizer step (fp16x2): its scales are measured on the data first, as PPO._update_hip does
+    pol.calibrate_h2(x, act, olp, adv, tgt, var, 0.2)
 for _ in range(REPS):
     pol.minibatch_grad(x, act, olp, adv, tgt, var, 0.2)
     pol.adam_step()
+if pol.h2_live():
+    assert int(pol.h2_overflow.item()) == 0
 xs = torch.randn(N, 73, device="cuda:0")
 eps = torch.randn(N, 18, device="cuda:0")
 a_o = torch.empty(N, 18, device="cuda:0"); lp_o = torch.empty(N, device="cuda:0"); v_o = torch.empty(N, device="cuda:0")

@@ -18,7 +18,7 @@ import os
 import re
 import sys
 
-WIDE_READS = ("mlp_fused_step_kernel", "mlp_forward_kernel", "mlp_backward_dx_kernel", "mlp_fwd_bwd_kernel", "mlp_grad_w_kernel", "mlp_grad_w_b3_kernel",
+WIDE_READS = ("mlp_fused_step_kernel", "mlp_fused_step_h2_kernel", "mlp_grad_reduce_h2_kernel", "mlp_forward_kernel", "mlp_backward_dx_kernel", "mlp_fwd_bwd_kernel", "mlp_grad_w_kernel", "mlp_grad_w_b3_kernel",
               "mlp_grad_reduce_kernel", "dqn_td_kernel", "dqn_grad_w_kernel", "dqn_grad_reduce_kernel", "dqn_forward_kernel", "dqn_act_kernel", "dqn_chain_kernel", "dqn_dw2_kernel")
 
 
