@@ -460,12 +460,10 @@ extern "C" hipError_t flyhip_launch_dqn_grad_w(const float* x, const float* h1, 
     T.l[3] = T.l[2];
     // dynamic LDS: two buffers of the largest layer's chunk: 2 x 32 x (260 + 260) floats = 130 KiB
     const size_t lds_bytes = sizeof(float) * 2 * GW_ROWS * (DQN_H + GW_PAD + DQN_H + GW_PAD);
-    static bool attr_set = false;
-    if (!attr_set) {
+    {       // (per launch: the attribute belongs to the CURRENT device)
         hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(dqn_grad_w_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (ea != hipSuccess) return ea;
-        attr_set = true;
     }
     hipLaunchKernelGGL(dqn_grad_w_kernel, dim3(first), dim3(GW_THREADS), lds_bytes, (hipStream_t)stream, T, (long)n);
     hipError_t e = hipGetLastError();
@@ -491,13 +489,12 @@ extern "C" hipError_t flyhip_launch_dqn_adam(float* P, float* PF, float* PT, flo
 // ---- the fused update: dqn_chain_kernel + dqn_dw2_kernel + the fixed-order reduction of their per-workgroup slabs -----------------
 static int dqn_cus()
 {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t pr;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
-    }
-    return cus;
+    static int cus[16] = {0};        // per DEVICE: a process may drive more than one
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (!cus[dev]) cus[dev] = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256;
+    return cus[dev];
 }
 
 static unsigned long long* g_dqn_stamps = nullptr;       // diagnostics (tools/stamp_dqn.py): u64 [workgroups][64], normally null
@@ -517,14 +514,12 @@ extern "C" hipError_t flyhip_launch_dqn_fused_update(const float* P, const uint1
     if (ntiles <= 0 || ntiles + 4096 >= (1L << 31)) return hipErrorInvalidValue;          // the kernels count tiles in 32 bits
     const int cus = dqn_cus();
     const int grid = (int)(ntiles < cus ? ntiles : cus);
-    static bool attr_set = false;
-    if (!attr_set) {
+    {       // (per launch: the attribute belongs to the CURRENT device)
         hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(dqn_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             DF_LDS_BYTES);
         if (ea != hipSuccess) return ea;
         ea = hipFuncSetAttribute(reinterpret_cast<const void*>(dqn_dw2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW2_LDS_BYTES);
         if (ea != hipSuccess) return ea;
-        attr_set = true;
     }
     float* ws1 = workspace;
     float* ws2 = ws1 + (long)cus * DF_STRIDE1;

@@ -219,17 +219,15 @@ extern "C" hipError_t flyhip_launch_rollout_all(const FlyConfig* dcfg, const Fly
     const char* fs_env = getenv("FLY_ROLLOUT_FS");               // read per launch: the tests flip it inside one process
     const bool fs_off = fs_env != nullptr && fs_env[0] == '0';
     if (PB && n % BM == 0 && !fs_off) {       // the policy body in the fused step's style (A/B: FLY_ROLLOUT_FS=0); persistent over tiles
-        static bool attr_set[4] = {false, false, false, false};
         const bool multi = (int)grid.x > cus;
         const int si = (stamps ? 1 : 0) + (multi ? 2 : 0);
         const void* fn = si == 0 ? reinterpret_cast<const void*>(rollout_all_fs_kernel<false, false>)
                        : si == 1 ? reinterpret_cast<const void*>(rollout_all_fs_kernel<true, false>)
                        : si == 2 ? reinterpret_cast<const void*>(rollout_all_fs_kernel<false, true>)
                                  : reinterpret_cast<const void*>(rollout_all_fs_kernel<true, true>);
-        if (!attr_set[si]) {
+        {       // (per launch: the attribute belongs to the CURRENT device)
             hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, FR_LDS_BYTES);
             if (ea != hipSuccess) return ea;
-            attr_set[si] = true;
         }
 #define RAFS_LAUNCH(S_, M_)                                                                                                           \
         hipLaunchKernelGGL((rollout_all_fs_kernel<S_, M_>), grid_fs, dim3(THREADS), FR_LDS_BYTES, (hipStream_t)stream, dcfg, *b, P, PB,   \
@@ -445,12 +443,10 @@ extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, 
     // dynamic LDS: two buffers of the largest layer's chunk (padded pitches): 2 x 32 x (136 + 264) floats = 100 KiB
     const size_t lds_bytes = sizeof(float) * 2 * GW_ROWS * (MLP_H2 + GW_PAD + MLP_H1 + GW_PAD);
     static_assert(MLP_H1 + GW_PAD + 96 <= MLP_H2 + GW_PAD + MLP_H1 + GW_PAD, "layer 1 chunk fits");
-    static bool attr_set = false;
-    if (!attr_set) {
+    {       // (per launch: the attribute belongs to the CURRENT device)
         hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_grad_w_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (ea != hipSuccess) return ea;
-        attr_set = true;
     }
     if (gemm_b3) {
         // two buffers of three bf16 term planes of a chunk: layers 1 / 2 stage 16 rows x (288 + 160) columns (84 KiB),
@@ -458,12 +454,10 @@ extern "C" hipError_t flyhip_launch_mlp_grad_w(const float* x, const float* h1, 
         const size_t b3_bytes = 2 * 3 * GB_ROWS_L3 * 2 * gb_pitch<MLP_H3>() * sizeof(u16);
         static_assert(16 * (gb_pitch<MLP_H1>() + gb_pitch<MLP_H2>()) <= GB_ROWS_L3 * 2 * gb_pitch<MLP_H3>() &&
                       GB_ROWS_L4 * (gb_pitch<MLP_OUT>() + gb_pitch<MLP_H3>()) <= GB_ROWS_L3 * 2 * gb_pitch<MLP_H3>(), "layer 3's chunk is the largest");
-        static bool b3_attr_set = false;
-        if (!b3_attr_set) {
+        {       // (per launch: the attribute belongs to the CURRENT device)
             hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_grad_w_b3_kernel),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)b3_bytes);
             if (ea != hipSuccess) return ea;
-            b3_attr_set = true;
         }
         hipLaunchKernelGGL(mlp_grad_w_b3_kernel, dim3(first), dim3(GW_THREADS), b3_bytes, (hipStream_t)stream, T, (long)n);
     } else {
@@ -484,13 +478,12 @@ extern "C" void flyhip_debug_set_fused_grid(int grid) { g_fused_grid_override = 
 extern "C" int flyhip_debug_get_fused_grid(void) { return g_fused_grid_override; }
 static int fused_cus()
 {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t pr;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
-    }
-    return cus;
+    static int cus[16] = {0};        // per DEVICE: a process may drive more than one
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (!cus[dev]) cus[dev] = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256;
+    return cus[dev];
 }
 static int fused_grid(int64_t n)
 {
@@ -513,7 +506,6 @@ extern "C" hipError_t flyhip_launch_mlp_fused_grad(const float* P, const uint16_
                                                    int* norm_step, float* loss_part, float* const* dump, void* stream)
 {
     const int grid = fused_grid(n);
-    static bool attr_set[3] = {false, false, false};
     FusedDump d = {};
     // debug_dump: 8 pointers = the chain dump (tests); ONE pointer followed by NULL = a stamp buffer (tools/stamp_fused.py)
     const int mode = dump == nullptr ? 0 : (dump[1] == nullptr ? 2 : 1);
@@ -522,10 +514,9 @@ extern "C" hipError_t flyhip_launch_mlp_fused_grad(const float* P, const uint16_
     const void* fn = mode == 0 ? reinterpret_cast<const void*>(mlp_fused_step_kernel<0>)
                    : mode == 1 ? reinterpret_cast<const void*>(mlp_fused_step_kernel<1>)
                                : reinterpret_cast<const void*>(mlp_fused_step_kernel<2>);
-    if (!attr_set[mode]) {
+    {           // (per launch: the attribute belongs to the CURRENT device)
         hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, FS_LDS_BYTES);
         if (ea != hipSuccess) return ea;
-        attr_set[mode] = true;
     }
 #define FS_LAUNCH(M_)                                                                                                             \
     hipLaunchKernelGGL(mlp_fused_step_kernel<M_>, dim3(grid), dim3(THREADS), FS_LDS_BYTES, (hipStream_t)stream, P, PB, PTB, x,     \

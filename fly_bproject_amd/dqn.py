@@ -293,6 +293,12 @@ class DQN:
             self._fu_images = torch.empty(int(lib.dqn_fused_image_halves(C.c_int64(S * n))), dtype=torch.int16, device=self.device)
             self._fu_ws = torch.empty(int(lib.dqn_fused_workspace_floats()), device=self.device)
             self._fu_loss = torch.zeros(tiles, device=self.device)
+        if getattr(self, "_fu_S", 0) < S:
+            # the chunk tables have a capacity of their own: an update of MORE chunks over no more rows (8 x 4096 after 4 x 8192)
+            # must not walk DqnChunk records past the end of a table sized for the earlier split
+            if getattr(self, "_fu_tab", None):
+                torch.cuda.synchronize(self.device)           # copies from the old pinned tables may still be in flight
+            self._fu_S = S
             self._fu_tab = [(torch.empty((S, 5), dtype=torch.int64, pin_memory=True), torch.empty((S, 5), dtype=torch.int64, device=self.device),
                              [None]) for _ in range(4)]
             self._fu_i = 0

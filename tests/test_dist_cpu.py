@@ -140,3 +140,73 @@ def test_bench_dead_rank_fails_fast():
 def test_bench_refuses_a_launcher_that_disagrees_with_gpus():
     r, lines = _run_bench(["--gpus", "2", "--dry_run"], {"WORLD_SIZE": "1", "RANK": "0"})
     assert r.returncode != 0 and not lines
+
+
+# ---- the PRODUCT's gradient layout through the same two-rank exchange -------------------------------------------------------
+# PPO._update_hip does not all-reduce 69 587 autograd views: it all-reduces the PACKED gradient the kernels write (74 272 floats in
+# the layout of csrc/mlp_layout.h: K padded to 80 for layer 1, the two heads stacked into one 32 x 128 last layer, structural
+# zeros and padding masked), in this order: local reduce -> exchange (sum) -> x 1/world inside the optimizer launch -> the clip sees
+# the GLOBAL gradient; element 76 (a masked padding column of W1) is the "this gradient is invalid" mark that must reach every rank.
+def _packed_grad(pol, net):
+    """The packed gradient mlp_grad_w / mlp_fused_grad would leave for `net`'s current .grad (masked positions carry junk there: 7.0)."""
+    from fly_bproject_amd.policy import PACKED
+    G = torch.full((PACKED,), 7.0)
+    for name, view in pol.views.items():
+        idx = torch.arange(PACKED).as_strided(view.shape, view.stride(), view.storage_offset())
+        G[idx.reshape(-1)] = dict(net.named_parameters())[name].grad.reshape(-1)
+    return G
+
+
+def _packed_worker(rank, world, port, out_dir, mark_rank):
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    from fly_bproject_amd.policy import ERR_SLOT, PackedPolicy
+    from fly_bproject_amd.ppo import Net
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    torch.manual_seed(7)
+    net = Net(73, 18)
+    pol = PackedPolicy(net, "cpu")                   # layout tables only: views, grad_mask (no kernel is launched on the CPU)
+    assert float(pol.grad_mask[ERR_SLOT]) == 0.0     # the mark lives in a masked element
+    full = _batch(3, 256)
+    mine = tuple(t[rank * 128:(rank + 1) * 128] for t in full)
+    agent = _bare_agent(net, torch.full((18,), 0.15))
+    agent.minibatch_loss(*mine).backward()           # local minibatch, inv_batch = 1 / local rows (as minibatch_grad)
+    G = _packed_grad(pol, net)
+    G[ERR_SLOT] = 1.0 if rank == mark_rank else 0.0  # what mlp_grad_reduce writes: 1 on the rank whose launch was refused
+    dist.all_reduce(G, op=dist.ReduceOp.SUM)         # the exchange (RCCL on the GPUs), 297 KB
+    scale = 1.0 / world                              # mlp_adam_step(grad_scale = 1 / world, self_norm): the clip sees the global gradient
+    g = G * scale * pol.grad_mask
+    norm = float(torch.sqrt((g.double() ** 2).sum()))
+    torch.save({"G": G, "norm": norm, "mark": float(G[ERR_SLOT])}, os.path.join(out_dir, "packed%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mark_rank", [-1, 1])
+def test_two_rank_gloo_packed_gradient_matches_single_process(tmp_path, mark_rank):
+    """World size 2 over gloo on the packed 74 272-float gradient: both ranks end with the same buffer; its masked part times 1 / world
+    equals the single-process gradient of the concatenated batch (and so does the clip norm); junk in masked positions never
+    reaches the norm; an invalid-gradient mark set on ONE rank arrives non-zero on BOTH (mlp_adam_step then refuses the step on
+    every rank alike), an unmarked exchange arrives as exactly 0."""
+    sys.path.insert(0, REPO)
+    from fly_bproject_amd.policy import ERR_SLOT, PACKED, PackedPolicy
+    from fly_bproject_amd.ppo import Net
+    port = _free_port()
+    mp.spawn(_packed_worker, args=(2, port, str(tmp_path), mark_rank), nprocs=2, join=True)
+    r = [torch.load(tmp_path / ("packed%d.pt" % k), weights_only=True) for k in range(2)]
+    assert torch.equal(r[0]["G"], r[1]["G"]) and r[0]["norm"] == r[1]["norm"]
+    assert r[0]["mark"] == r[1]["mark"] == (1.0 if mark_rank >= 0 else 0.0)
+    torch.manual_seed(7)
+    net = Net(73, 18)
+    pol = PackedPolicy(net, "cpu")
+    agent = _bare_agent(net, torch.full((18,), 0.15))
+    agent.minibatch_loss(*_batch(3, 256)).backward()
+    want = _packed_grad(pol, net) * pol.grad_mask
+    got = r[0]["G"] * 0.5 * pol.grad_mask
+    assert int(pol.grad_mask.sum()) == 69587 and got.numel() == PACKED == 74272
+    # the Huber term enters as a scalar MEAN per minibatch (ppo.py:194, Q7): the mean of two half-batch means is the full-batch mean, so
+    # the two-rank gradient is the single-process one up to fp32 summation order
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=2e-5 * float(want.abs().max()))
+    np.testing.assert_allclose(r[0]["norm"], float(torch.sqrt((want.double() ** 2).sum())), rtol=1e-5)
+    assert float(got[ERR_SLOT]) == 0.0               # masked: the mark itself never moves a weight or enters the norm

@@ -298,3 +298,26 @@ def test_dqn_runs_end_to_end():
     a = agent.act(agent.env.obs_buf, 0.0)
     assert a.shape == (256,) and float(a.abs().max()) <= 1.0
     agent.exit()
+
+
+@pytest.mark.gpu
+def test_dqn_fused_update_with_more_chunks_over_no_more_rows():
+    """`DQN.update(chunks)` is a public entry that callers give varying splits: 2 x 4096 rows, then 8 x 1024 -- MORE chunks over no more
+    rows.  The chunk tables have a capacity of their own (round 4's advisor: they used to be regrown only when the row count grew, and
+    the second call walked DqnChunk records past the end of a table sized for two).  Both calls against torch autograd."""
+    torch.manual_seed(5)
+    d = _bare_dqn(rows=8192, fused=True)
+    for parts, n in ((2, 4096), (8, 1024), (3, 2048)):
+        chunks = [(torch.randn(n, 73, device="cuda:0"), torch.rand(n, device="cuda:0") * 2 - 1, torch.randn(n, device="cuda:0") * 2,
+                   torch.randn(n, 73, device="cuda:0"), (torch.rand(n, device="cuda:0") > 0.1).float()) for _ in range(parts)]
+        obs, act, rew, nxt, done = (torch.cat([c[i] for c in chunks]) for i in range(5))
+        B = parts * n
+        idx = torch.round(0.5 * (act + 1) * 17).long()
+        q_val = d.q(obs)[torch.arange(B), idx]
+        with torch.no_grad():
+            target = rew + 0.99 * d.q_target(nxt).max(1)[0] * done
+        loss = torch.nn.functional.smooth_l1_loss(q_val, target)
+        got_loss = d.update(chunks)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(float(got_loss), float(loss), rtol=2e-5)
+        assert d._fu_S >= parts and d._fu_tab[0][0].shape[0] >= parts

@@ -223,7 +223,23 @@ def test_fused_step_vs_oracle_resynced(variant, n):
         push_state(env, s)
         env.step(cuda(a))
         got = pull_state(env)
+        # the same physics in float64 from the same pre-physics state (fly.py:626-663: scale, then reset before simulate -- bigGrav)
+        pre = s.copy()
+        pre.targets[:] = O.scale_actions(cfg, a)
+        flagged = pre.reset != 0
+        if not cfg.reset_after_sim:
+            O.reset_masked(cfg, pre)
+        r64, q64, qd64, _ = O.physics_step_f64(cfg, pre.root, pre.dof_pos, pre.dof_vel, pre.targets)
         O.env_step(cfg, s, a)
+        live = ~flagged if cfg.reset_after_sim else np.ones(n, bool)       # (lowGrav: a flagged env ends the step in the reset pose)
+        # DERIVED velocity tolerance (fly.py:624-681's step is 15 stiff substeps in fp32): an element may miss float64 by the stated
+        # 5e-3 (abs + rel) -- or by K = 4 times what the fp32 ORACLE itself misses float64 by on that very element, whichever is larger.
+        # So the kernel's tail is bounded by the restatement's own sensitivity at that state, not by a count of outliers.
+        K = 4.0
+        for hip, f32, f64 in ((got.root[:, 7:], s.root[:, 7:], r64[:, 7:]), (got.dof_vel, s.dof_vel, qd64)):
+            bound = np.maximum(5e-3 * (1.0 + np.abs(f64)), K * np.abs(f32.astype(np.float64) - f64))
+            over = (np.abs(hip.astype(np.float64) - f64) > bound) & live[:, None]
+            assert not over.any(), (t, int(over.sum()), float(np.abs(hip - f64)[over].max()), float(np.abs(f32 - f64)[over].max()))
         assert np.array_equal(got.targets, s.targets)
         assert np.array_equal(got.progress, s.progress), t
         # masks are bit-exact wherever the deciding quantities are not within rounding of a threshold
@@ -235,10 +251,11 @@ def test_fused_step_vs_oracle_resynced(variant, n):
         assert np.array_equal(got.reset[safe], s.reset[safe]), t
         np.testing.assert_allclose(got.root[:, :7], s.root[:, :7], rtol=2e-4, atol=2e-4)
         lin = [0, 1, 2, 3, 4, 5, 6, 10, 11]
-        # (velocity columns after 15 stiff substeps: 5e-3 holds for all but a few in 10^5 values -- at 8192 envs x 48 steps
-        # the tail shows: at most 1 in 10^4 may exceed it, none 2e-2)
-        dv = np.abs(got.obs[safe][:, lin] - s.obs[safe][:, lin]) - 5e-3 * np.abs(s.obs[safe][:, lin])
-        assert (dv > 5e-3).mean() <= (1e-4 if n > 1024 else 0.0) and dv.max() < 2e-2, (t, float(dv.max()), float((dv > 5e-3).mean()))
+        # observation columns built from those velocities (rotated into the body frame): against the fp32 oracle, the same rule with
+        # the oracle's own distance from float64 on the env's root velocities as the element's sensitivity
+        sens = K * np.abs(s.root[:, 7:].astype(np.float64) - r64[:, 7:]).max(axis=1)
+        dv = np.abs(got.obs[:, lin] - s.obs[:, lin]) - 5e-3 * (1.0 + np.abs(s.obs[:, lin])) - 2.5 * sens[:, None]      # (a rotation mixes three components)
+        assert not (safe & live).any() or dv[safe & live].max() <= 0.0, (t, float(dv[safe & live].max()))
         for col in (7, 8, 9, 66):                           # angles live on a circle: 0 == 2*pi
             dang = np.abs((got.obs[safe][:, col] - s.obs[safe][:, col] + np.pi) % (2 * np.pi) - np.pi)
             assert dang.max() < 5e-3, (t, col, dang.max())

@@ -452,3 +452,40 @@ def test_log_throughput_flag_extends_the_score_line_only_when_asked():
     rates = [float(re.search(r"Env-steps/s ([0-9.e+]+)$", ln).group(1)) for ln in timed[1:]]
     assert all(r > 1e5 for r in rates), rates
     assert torch.equal(res[False][1], res[True][1])
+
+
+@pytest.mark.parametrize("n", [8192, 16384])
+def test_one_launch_rollout_is_deterministic_run_to_run(n):
+    """`ppo_rollout_all` twice on identical inputs (same seed -> same weights, same reset state, same eps): every row it writes --
+    observations, actions, log-probs, values, rewards, per-step reset / progress flags -- must be bit-equal run to run, over a WHOLE
+    rollout and the first steps of the next one (after an update: changed weights).  8192 envs = rollout_all_fs_kernel<false, false>
+    at one tile per CU (T = 80), 16384 = its persistent-over-tiles instantiation (T = 32).  The kernel runs the fused step's chain
+    GEMMs as inline-asm MFMAs (policy_tile_fs): an operand hazard there shows as run-to-run differences in the last bits INSIDE every
+    parity tolerance -- the defect class round 4's b6e3caf fixed in the DQN kernel, which only a determinism test can see
+    (tools/check_mfma_hazard.py is the static half of this check)."""
+    from fly_bproject_amd.ppo import PPO
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            agent = PPO(make_args(n))
+            assert agent.persistent_rollout and agent.policy.gemm_infer == "bf16x3"
+            T = agent.rollout_size
+            assert T == 16 * (40960 // n)
+            for _ in range(T):
+                agent.run()
+            torch.cuda.synchronize()
+            first = [t.clone() for t in (agent._obs_ring, agent.all_acts, agent.all_log_prob, agent._v_ring[:T], agent.all_reward,
+                                         agent._reset_rows, agent._progress_rows)]
+            assert agent.optim_step == 75
+            for _ in range(T // 2):                         # into the next rollout: the launch has run all T steps on the NEW weights
+                agent.run()
+            torch.cuda.synchronize()
+            second = [t.clone() for t in (agent._obs_ring, agent.all_acts, agent.all_log_prob, agent._v_ring[:T], agent.all_reward,
+                                          agent._reset_rows, agent._progress_rows, agent.policy.P)]
+        runs.append(first + second)
+        agent.exit()
+    for i, (a, b) in enumerate(zip(*runs)):
+        assert torch.isfinite(a.float()).all(), i
+        assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
+    assert int(runs[0][5].sum()) > 0                        # episodes ended inside the rollout: the reset path ran too

@@ -5,7 +5,9 @@ allocation makes it assemble an operand tuple with a v_mov (or any VALU) right i
 (timing dependent: run-to-run differences in the last bits).  For every csrc/*.hip: compile to ISA, and for every v_mfma inside an
 #ASMSTART / #ASMEND block report VALU writes to its A / B / C operand registers within the last WAIT wait states -- and, the other
 direction, any vector / LDS / memory instruction that reads such an MFMA's result within RESULT_WAIT wait states (what fs_mfma_settle
-is there for).
+is there for) -- and any MFMA (the compiler's own included) that takes such a result as its A or B operand that soon (an MFMA may
+chain on a predecessor's result as its ACCUMULATOR back to back; as a multiplicand it may not).  The report counts the asm MFMAs it
+inspected per kernel, so that "none found" can be told from "none looked at".
 
     python tools/check_mfma_hazard.py [file.hip ...]        exit code 1 if anything is found
 """
@@ -31,6 +33,17 @@ def regs(tok):
     return {int(m.group(1))} if m else set()
 
 
+def demangle_short(sym):
+    """`mlp_fused_step_kernel<0>`-style name of a mangled kernel symbol."""
+    m = re.findall(r"\d+([a-z][a-z0-9_]*kernel)(I(?:L[ib]\d+E)+E)?", sym)
+    if not m:
+        return sym[:60]
+    name, targs = m[-1]
+    if targs:
+        name += "<" + ", ".join(re.findall(r"L[ib](\d+)E", targs)) + ">"
+    return name
+
+
 def check(path):
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
@@ -38,14 +51,16 @@ def check(path):
                                "-I" + CSRC, "-Wno-unused-function", "-S", "--cuda-device-only", "-o", out, path], stderr=subprocess.DEVNULL)
         lines = open(out).read().split("\n")
     found = []
+    counts = {}          # kernel -> asm MFMAs inspected
     in_asm = False
     hist = []            # (wait states ago accumulates, written regs, text) of recent instructions
     res = []             # (wait states ago, result regs, text) of recent asm MFMAs: a non-MFMA reader needs RESULT_WAIT wait states
     func = "?"
     for ln, raw in enumerate(lines, 1):
         s = raw.strip()
-        if s.endswith(":") and not s.startswith(".") and not s.startswith(";"):
-            func = s[:-1][:60]
+        m = re.match(r"^(_Z[\w$]+):", raw)          # a kernel's label (mangled; a `; @name` comment may follow)
+        if m:
+            func = demangle_short(m.group(1))
         if "#ASMSTART" in s:
             in_asm = True
             continue
@@ -62,9 +77,15 @@ def check(path):
             continue
         args = s[len(op):].split(",")
         if op.startswith("v_mfma") and in_asm:
+            counts[func] = counts.get(func, 0) + 1
             src = regs(args[1]) | regs(args[2]) | (regs(args[3]) if len(args) > 3 else set())      # A, B and the accumulator input
             for w, r, t in hist:
                 if w < WAIT and r & src:
+                    found.append((os.path.basename(path), func, ln, t, s))
+        if op.startswith("v_mfma"):     # any MFMA multiplying by an asm MFMA's fresh result (A / B operand; chaining on C is fine)
+            ab = regs(args[1]) | regs(args[2])
+            for w, r, t in res:
+                if w < RESULT_WAIT and r & ab:
                     found.append((os.path.basename(path), func, ln, t, s))
         # the other direction: something that is not an MFMA reads an asm MFMA's result before it is written (fs_mfma_settle's job)
         if not op.startswith("v_mfma") and (op.startswith("v_") or op.startswith("ds_") or op.startswith("global_") or op.startswith("scratch_")):
@@ -82,17 +103,21 @@ def check(path):
         hist = [(w + 1, r, t) for (w, r, t) in hist if w + 1 < WAIT + 2]
         if op.startswith("v_") and not op.startswith("v_mfma") and not op.startswith("v_cmp"):
             hist.append((0, regs(args[0]), s))
-    return found
+    return found, counts
 
 
 def main():
     files = sys.argv[1:] or sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    bad = []
+    bad, looked = [], 0
     for f in files:
-        bad += check(f)
+        found, counts = check(f)
+        bad += found
+        for k, n in sorted(counts.items()):
+            print("%s %s: %d asm MFMAs inspected" % (os.path.basename(f), k, n))
+            looked += n
     for b in bad:
         print("%s %s line %d: `%s` in front of `%s`" % b)
-    print("%d hazard(s) in %d file(s)" % (len(bad), len(files)))
+    print("%d hazard(s) among %d asm MFMAs in %d file(s)" % (len(bad), looked, len(files)))
     return 1 if bad else 0
 
 
