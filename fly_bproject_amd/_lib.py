@@ -50,7 +50,8 @@ SYMBOLS = {
     "mlp_fused_grad": [_P] * 3 + [_P, _L] + [_P] * 5 + [_F, _F] + [_P] * 6 + [C.POINTER(_P), _P],
     "mlp_fused_h2_workspace_floats": [],
     "mlp_fused_grad_h2": [_P] * 5 + [_I, _P, _L] + [_P] * 5 + [_F, _F] + [_P] * 6 + [C.POINTER(_P), _P],
-    "mlp_adam_step": [_P] * 10 + [_F, _F, _F, _F, _F, _F, _P, _I, _P, _P, _P, _P, _P, _P] + [_P] * 4 + [_P],
+    "mlp_h2_rescale": [_P] * 7,
+    "mlp_adam_step": [_P] * 10 + [_F, _F, _F, _F, _F, _F, _P, _I, _P, _P, _P, _P, _P, _P] + [_P] * 3 + [_I, _P],
     "dqn_eps_greedy": [_P, _P, _P, _F, _I, _P, _L, _P],
     "dqn_huber_td": [_P, _P, _P, _P, _P, _F, _I, _L, _P, _P, _P],
     "dqn_forward": [_P, _P, _P, _L, _P, _P],

@@ -64,7 +64,9 @@ extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PF, float* PT, con
                                              float max_norm, float grad_scale, float* norm_ws, int norm_ready,
                                              uint16_t* PB, uint16_t* PTB, const int* idx_fb, const int* idx_tb,
                                              int* step_out, const int* grad_invalid, uint16_t* PH, uint16_t* PTH,
-                                             float* h2_scales, float* h2_wmax, void* stream);
+                                             float* h2_scales, int h2_rescale, void* stream);
+extern "C" hipError_t flyhip_launch_mlp_h2_rescale(const float* P, const int* idx_fb, const int* idx_tb, uint16_t* PH, uint16_t* PTH,
+                                                   float* h2_scales, void* stream);
 extern "C" int64_t flyhip_mlp_fused_h2_workspace_floats(void);
 extern "C" hipError_t flyhip_launch_mlp_fused_grad_h2(const float* P, const uint16_t* PH, const uint16_t* PTH, float* fsc, int* ovf,
                                                       int freeze, const float* x, int64_t n, const float* action,
@@ -464,6 +466,15 @@ int mlp_fused_grad(const float* params, const uint16_t* params_b3, const uint16_
 
 int64_t mlp_fused_h2_workspace_floats(void) { return flyhip_mlp_fused_h2_workspace_floats(); }
 
+int mlp_h2_rescale(const float* params, const int32_t* idx_b3, const int32_t* idx_t_b3, uint16_t* params_h2, uint16_t* params_t_h2,
+                   float* h2_scales, void* stream)
+{
+    if (!params || !idx_b3 || !idx_t_b3 || !params_h2 || !params_t_h2 || !h2_scales) return fail(FLY_E_ARG, "mlp_h2_rescale: null pointer");
+    hipError_t e = flyhip_launch_mlp_h2_rescale(params, idx_b3, idx_t_b3, params_h2, params_t_h2, h2_scales, stream);
+    if (e != hipSuccess) return hip_fail(e, "mlp_h2_rescale launch");
+    return FLY_OK;
+}
+
 int mlp_fused_grad_h2(const float* params, const uint16_t* params_h2, const uint16_t* params_t_h2, float* h2_scales,
                       int32_t* h2_overflow, int32_t freeze, const float* x, int64_t n, const float* action,
                       const float* old_logp, const float* adv, const float* target, const float* var, float inv_batch,
@@ -495,19 +506,19 @@ int mlp_adam_step(float* params, float* params_frag, float* params_t_frag, const
                   float* exp_avg_sq, int32_t* step, float lr, float beta1, float beta2, float eps,
                   float max_norm, float grad_scale, float* norm_ws, int32_t norm_ready, uint16_t* params_b3,
                   uint16_t* params_t_b3, const int32_t* idx_b3, const int32_t* idx_t_b3, int32_t* step_out,
-                  const int32_t* grad_invalid, uint16_t* params_h2, uint16_t* params_t_h2, float* h2_scales, float* h2_wmax,
+                  const int32_t* grad_invalid, uint16_t* params_h2, uint16_t* params_t_h2, float* h2_scales, int32_t h2_rescale,
                   void* stream)
 {
     if (params_b3 && (!params_t_b3 || !idx_b3 || !idx_t_b3))
         return fail(FLY_E_ARG, "mlp_adam_step: params_b3 needs params_t_b3, idx_b3 and idx_t_b3");
-    if (params_h2 && (!params_t_h2 || !h2_scales || !h2_wmax || !params_b3))
-        return fail(FLY_E_ARG, "mlp_adam_step: params_h2 needs params_t_h2, h2_scales, h2_wmax and the bf16x3 planes with their index maps");
+    if (params_h2 && (!params_t_h2 || !h2_scales || !params_b3))
+        return fail(FLY_E_ARG, "mlp_adam_step: params_h2 needs params_t_h2, h2_scales and the bf16x3 planes with their index maps");
     if (!params || !params_frag || !params_t_frag || !idx_frag || !idx_t_frag || !grad || !mask || !exp_avg ||
         !exp_avg_sq || !step || !norm_ws)
         return fail(FLY_E_ARG, "mlp_adam_step: null pointer");
     hipError_t e = flyhip_launch_mlp_adam(params, params_frag, params_t_frag, idx_frag, idx_t_frag, grad, mask, exp_avg, exp_avg_sq, step, lr, beta1, beta2,
                                           eps, max_norm, grad_scale, norm_ws, norm_ready, params_b3, params_t_b3, idx_b3, idx_t_b3,
-                                          step_out, grad_invalid, params_h2, params_t_h2, h2_scales, h2_wmax, stream);
+                                          step_out, grad_invalid, params_h2, params_t_h2, h2_scales, h2_rescale, stream);
     if (e != hipSuccess) return hip_fail(e, "mlp_adam_step launch");
     return FLY_OK;
 }

@@ -549,7 +549,7 @@ extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PF, float* PT, con
                                              float max_norm, float grad_scale, float* norm_ws, int norm_ready,
                                              uint16_t* PB, uint16_t* PTB, const int* idx_fb, const int* idx_tb,
                                              int* step_out, const int* grad_invalid, uint16_t* PH, uint16_t* PTH,
-                                             float* h2_scales, float* h2_wmax, void* stream)
+                                             float* h2_scales, int h2_rescale, void* stream)
 {
     int nparts = ADAM_BLOCKS;
     float part_scale = 1.0f;
@@ -566,6 +566,13 @@ extern "C" hipError_t flyhip_launch_mlp_adam(float* P, float* PF, float* PT, con
     }
     hipLaunchKernelGGL(mlp_adam_apply_kernel, dim3(ADAM_BLOCKS), dim3(ADAM_THREADS), 0, (hipStream_t)stream, P, PF, PT,
                        idx_f, idx_t, G, mask, m, v, step, lr, beta1, beta2, eps, max_norm, grad_scale, norm_ws, nparts,
-                       part_scale, PB, PTB, idx_fb, idx_tb, step_out, grad_invalid, PH, PTH, h2_scales, h2_wmax);
+                       part_scale, PB, PTB, idx_fb, idx_tb, step_out, grad_invalid, PH, PTH, h2_scales, h2_rescale);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t flyhip_launch_mlp_h2_rescale(const float* P, const int* idx_fb, const int* idx_tb, uint16_t* PH, uint16_t* PTH,
+                                                   float* h2_scales, void* stream)
+{
+    hipLaunchKernelGGL(mlp_h2_rescale_kernel, dim3(1), dim3(H2_RESCALE_THREADS), 0, (hipStream_t)stream, P, idx_fb, idx_tb, PH, PTH, h2_scales);
     return hipGetLastError();
 }

@@ -102,7 +102,7 @@ def build_plane_maps():
 
 # fp16x2 planes of the fused optimizer step (csrc/mlp_fused_h2.inc): PB's / PTB's layout with two terms per k block
 PH_HALVES, PTH_HALVES = PB_HALVES * 2 // 3, PTB_HALVES * 2 // 3
-H2_SCALE_FLOATS, H2_INV, H2_W0, ADAM_BLOCKS = 48, 16, 8, 291
+H2_SCALE_FLOATS, H2_INV, H2_W0 = 48, 16, 8
 H2_CLASSES = ("x", "h1", "h2", "h3", "dz4", "dz3", "dz2", "dz1")
 
 
@@ -115,9 +115,9 @@ def split_f16x2(w, scale):
 
 
 def h2_weight_scale(wmax):
-    """The power of two mlp_adam_step gives a layer whose largest |w| was `wmax`: the maximum lands in [2^11, 2^12)."""
+    """The power of two mlp_h2_rescale gives a layer whose largest |w| is `wmax`: max(wmax, 2^-4) lands in [2^11, 2^12)."""
     import math
-    m = min(max(float(wmax), 2.0 ** -7), 2.0 ** 60)
+    m = min(max(float(wmax), 2.0 ** -4), 2.0 ** 60)
     return 2.0 ** (11 - math.floor(math.log2(m)))
 
 
@@ -167,10 +167,10 @@ class PackedPolicy:
         self.PH = torch.zeros(PH_HALVES, dtype=torch.int16, device=self.device)
         self.PTH = torch.zeros(PTH_HALVES, dtype=torch.int16, device=self.device)
         self.h2_scales = torch.zeros(H2_SCALE_FLOATS, dtype=torch.float32, device=self.device)
-        self.h2_wmax = torch.zeros(2 * ADAM_BLOCKS * 4, dtype=torch.float32, device=self.device)
         self.h2_overflow = torch.zeros(1, dtype=torch.int32, device=self.device)     # sticky: a launch's values did not fit fp16
         self.h2_freeze = False              # tests: the reduction leaves the scale table alone
         self.h2_calibrated = False
+        self._h2_steps_since_rescale = 0
         self.h2_suspended = False           # True while refused steps are redone on the bf16x3 kernel (the planes stay maintained)
         self.h2_overflows = 0               # updates in which the fp16x2 step was refused and redone on bf16x3
         self._h2_reset_scales()
@@ -254,25 +254,15 @@ class PackedPolicy:
         self.h2_calibrated = False
 
     def _refresh_planes_h2(self):
-        """fp16x2 weight planes and their per-layer scales from the master weights (what mlp_adam_step maintains step by step)."""
-        with torch.no_grad():
-            bounds = (OFF_W1, OFF_W2, OFF_W3, OFF_W4, PACKED)
-            wmax = torch.zeros(2, ADAM_BLOCKS, 4)
-            sc = self.h2_scales.cpu()
-            layer_scale = torch.ones(PACKED, device=self.device)
-            for l in range(4):
-                sel = self._src_fb[(self._src_fb >= bounds[l]) & (self._src_fb < bounds[l + 1])]
-                m = float(self.P[sel].abs().max())
-                wmax[:, 0, l] = m                               # both parities: whichever step comes next finds it
-                k = h2_weight_scale(m)
-                sc[H2_W0 + l], sc[H2_INV + H2_W0 + l] = k, 1.0 / k
-                layer_scale[bounds[l]:bounds[l + 1]] = k
-            self.h2_wmax.copy_(wmax.reshape(-1))
-            self.h2_scales.copy_(sc)
-            for dst_buf, src, dst in ((self.PH, self._src_fb, self._dst_fb), (self.PTH, self._src_tb, self._dst_tb)):
-                dh = (dst // 1536) * 1024 + dst % 1536
-                for term, plane in enumerate(split_f16x2(self.P[src], layer_scale[src])):
-                    dst_buf[dh + 512 * term] = plane
+        """fp16x2 weight planes and their per-layer scales from the master weights (`mlp_h2_rescale`: one small launch, no host sync).
+        The scales then stay fixed while mlp_adam_step splits the updated weights under them; an Adam step moves a weight by at most
+        3.2 lr, and overflowing needs a weight to travel 15/16 at least, so a call every `0.9 / (3.2 lr)` steps keeps fp16 safe."""
+        if self.device.type != "cuda":
+            return                                  # (layout-only uses of the class on the CPU: tests/test_dist_cpu.py)
+        p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+        _lib.check(self._lib.mlp_h2_rescale(p(self.P), p(self.idx_fb), p(self.idx_tb), p(self.PH), p(self.PTH), p(self.h2_scales),
+                                            _lib.stream_ptr()), "mlp_h2_rescale")
+        self._h2_steps_since_rescale = 0
 
     def _planes_live(self):
         return self._gemm == "bf16x3" or self.gemm_infer == "bf16x3"
@@ -321,9 +311,13 @@ class PackedPolicy:
 
     def _h2_args(self):
         if not self.h2_live():
-            return (None, None, None, None)
+            return (None, None, None, C.c_int(0))
         p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
-        return (p(self.PH), p(self.PTH), p(self.h2_scales), p(self.h2_wmax))
+        # a RESCALE step (the kernel re-derives the weight scales from the weights before it splits under them) often enough that a
+        # weight cannot have drifted out of the scale's 16x headroom: an Adam step moves it by at most 3.2 lr
+        rescale = self._h2_steps_since_rescale >= max(1, min(64, int(0.9 / (3.2 * self.lr))))
+        self._h2_steps_since_rescale = 1 if rescale else self._h2_steps_since_rescale + 1
+        return (p(self.PH), p(self.PTH), p(self.h2_scales), C.c_int(1 if rescale else 0))
 
     def pb_ptr(self):
         """Term planes for the UPDATE's forward (minibatch_grad); inference launches (rollout policy,

@@ -372,7 +372,7 @@ int mlp_adam_step(float* params, float* params_frag, float* params_t_frag, const
                   float max_norm, float grad_scale, float* norm_ws, int32_t norm_ready,
                   uint16_t* params_b3, uint16_t* params_t_b3, const int32_t* idx_b3,
                   const int32_t* idx_t_b3, int32_t* step_out, const int32_t* grad_invalid,
-                  uint16_t* params_h2, uint16_t* params_t_h2, float* h2_scales, float* h2_wmax, void* stream);
+                  uint16_t* params_h2, uint16_t* params_t_h2, float* h2_scales, int32_t h2_rescale, void* stream);
 
 /*
  * The same gradient in the fp16x2 arithmetic (csrc/mlp_fused_h2.inc): every fp32 operand of a GEMM is carried as TWO fp16 terms of
@@ -380,7 +380,10 @@ int mlp_adam_step(float* params, float* params_frag, float* params_t_frag, const
  * the six bf16 products of mlp_fused_grad: half the matrix time.  What it needs besides mlp_fused_grad's arguments:
  *   params_h2 / params_t_h2  the weights as two fp16 terms of w * s_layer (MLP_PH_HALVES_ABI / MLP_PTH_HALVES_ABI 16-bit words: the
  *                 layout of params_b3 / params_t_b3 with 1024-word blocks instead of 1536: term 0, term 1); mlp_adam_step
- *                 maintains them (params_h2 != NULL; it needs params_b3 and its index maps too) together with the weight scales;
+ *                 splits every updated weight into them (params_h2 != NULL; it needs params_b3 and its index maps too) under the
+ *                 layer scales h2_scales[8 .. 11]; a call with h2_rescale != 0 first re-derives those scales from the weights as they
+ *                 stand (max(max |w_layer|, 2^-4) -> [2^11, 2^12): 16x of headroom) and publishes them.  An Adam step moves a weight by
+ *                 <= 3.2 lr, so a rescale step at least every 0.9 / (3.2 lr) steps (the host: every 64) keeps the planes inside fp16;
  *   h2_scales     device float [MLP_H2_SCALE_FLOATS_ABI]: s[c] at [c], 1 / s[c] at [16 + c] for the classes c = 0 X, 1 H1, 2 H2,
  *                 3 H3, 4 dZ4, 5 dZ3, 6 dZ2, 7 dZ1, 8 .. 11 W1 .. W4; [32 + c] = the largest |scaled value| the last launch saw.
  *                 The launch READS the table and its reduction WRITES the activation / gradient entries for the NEXT launch (this
@@ -389,15 +392,16 @@ int mlp_adam_step(float* params, float* params_frag, float* params_t_frag, const
  *                 every launch marks its gradient invalid (grad[76] = 1, as mlp_grad_w does with a nonzero `err`) and does not
  *                 advance *norm_step, so mlp_adam_step refuses the step: the caller reads the step counter at the end of the
  *                 update, clears the word and redoes the refused steps, in order, with mlp_fused_grad;
- *   h2_wmax       (mlp_adam_step) device float [2][291][4]: per optimizer block and layer max |w|, double-buffered by step parity;
- *                 the scale of layer l's planes is taken from the previous step's maximum with 16x of headroom.
+ *   mlp_h2_rescale: the same scales and both plane buffers from `params` without an optimizer step (one slow block): before the
+ *                 first step and after any out-of-band change of the weights.
  * `workspace` holds mlp_fused_h2_workspace_floats() floats.  A first launch on a new network should be preceded by a few launches
  * whose result is discarded (scales converge in one launch per class that overflowed; fly_bproject_amd/policy.py: calibrate_h2).
  */
 #define MLP_PH_HALVES_ABI 147456
 #define MLP_PTH_HALVES_ABI 106496
 #define MLP_H2_SCALE_FLOATS_ABI 48
-#define MLP_H2_WMAX_FLOATS_ABI 2328
+int mlp_h2_rescale(const float* params, const int32_t* idx_b3, const int32_t* idx_t_b3, uint16_t* params_h2, uint16_t* params_t_h2,
+                   float* h2_scales, void* stream);
 int64_t mlp_fused_h2_workspace_floats(void);
 int mlp_fused_grad_h2(const float* params, const uint16_t* params_h2, const uint16_t* params_t_h2, float* h2_scales,
                       int32_t* h2_overflow, int32_t freeze, const float* x, int64_t n, const float* action,

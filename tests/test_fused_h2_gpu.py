@@ -153,7 +153,7 @@ def test_h2_scales_follow_the_data_and_the_planes_follow_the_weights():
     """After a launch every class's scale puts THAT launch's largest |value| into the class's window ([2^7, 2^8) for x / h1 .. h3,
     [2^2, 2^3) for dz4 .. dz1: csrc/mlp_fused_h2.inc, h2_target_exp); the
     weight planes mlp_adam_step maintains equal a fresh split of the weights under the scales it published, whose headroom over the
-    current max |w| is 8x .. 32x."""
+    current max |w| is 8x .. 64x (16x .. 32x when the scale was set; max |w| counted as 2^-4 at least)."""
     import math
     from fly_bproject_amd.policy import H2_INV, H2_W0, OFF_W1, OFF_W2, OFF_W3, OFF_W4, PACKED, split_f16x2
     n = 4099
@@ -179,7 +179,7 @@ def test_h2_scales_follow_the_data_and_the_planes_follow_the_weights():
         sel = pol._src_fb[(pol._src_fb >= bounds[l]) & (pol._src_fb < bounds[l + 1])]
         k = float(sc[H2_W0 + l])
         head = 65504.0 / (float(pol.P[sel].abs().max()) * k)
-        assert 8.0 <= head <= 32.5, (l, head)
+        assert 8.0 <= head <= 64.0, (l, head)
         layer_scale[bounds[l]:bounds[l + 1]] = k
     for buf, src, dst in ((pol.PH, pol._src_fb, pol._dst_fb), (pol.PTH, pol._src_tb, pol._dst_tb)):
         dh = (dst // 1536) * 1024 + dst % 1536

@@ -1,0 +1,32 @@
+#!/bin/bash
+# gpu_final.sh TAG -- on the MI355X box: everything a round's numbers come from, in one call (boxes are slow to get): the GPU tests, the
+# driver's bench line, the other configurations, the profile collection, the training curves of both optimizer-step arithmetics, the
+# fused step's stamps and the scale trace.  A step that TIMES OUT ends the script (no GPU step after a hang).
+TAG=${1:-r}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+step() {   # step NAME SECONDS cmd...
+    local name=$1 secs=$2; shift 2
+    timeout -k 10 "$secs" "$@"
+    local rc=$?
+    echo "[$name] rc=$rc"
+    if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "[$name] timed out: stopping"; exit $rc; fi
+    return $rc
+}
+step pytest 800 python -m pytest tests -m gpu -q > $OUT/tests.log 2>&1; tail -3 $OUT/tests.log
+step bench 400 python bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err
+step bench4096 200 python bench.py --num_envs 4096 --steps 5 --warmup 2 --no_cpu_baseline --no_dqn --no_alt_gemm > $OUT/bench_4096_envs.json 2> /dev/null
+step bench16384 200 python bench.py --num_envs 16384 --steps 5 --warmup 2 --no_cpu_baseline --no_dqn --no_alt_gemm > $OUT/bench_16384_envs.json 2> /dev/null
+step benchdqn 300 python bench.py --workload dqn --steps 10 --warmup 2 > $OUT/bench_dqn.json 2> /dev/null
+step curve_h2 300 python tools/train_curve.py 200 8192 hip bigGrav f16x2 > $OUT/training_curve_f16x2.txt 2>&1
+step curve_b3 300 python tools/train_curve.py 200 8192 hip bigGrav bf16x3 > $OUT/training_curve_bf16x3.txt 2>&1
+step stamp 200 python tools/stamp_fused.py 40960 f16x2 > $OUT/stamps_h2.txt 2>&1
+step timef 200 python tools/time_fused.py 40960 200 > $OUT/time_fused.txt 2>&1
+step trace 300 python tools/h2_scale_trace.py 30 > $OUT/scale_trace.txt 2>&1
+step arith 200 ./build_tools/mfma_chain_interleave arith > $OUT/arith_replica.txt 2>&1
+step split 100 ./build_tools/h2_wave_split > $OUT/wave_split.txt 2>&1
+step probe 60 ./build_tools/f16_probe > $OUT/f16_probe.txt 2>&1
+cd /tmp && cd $GRAFT_REPO_ROOT
+step profiles 1100 bash tools/collect_profiles.sh $TAG/prof > $OUT/collect.log 2>&1
+echo "final done"
