@@ -318,7 +318,12 @@ def fused_step_clock(pol, batch, h2):
         whole = (s[:, 63, 1] - s[:, 62, 0]).astype("float64")
         real_us = ((s[:, 63, 2] & 0xffffffffffff) - (s[:, 62, 1] & 0xffffffffffff)).astype("float64") / 100.0
         ok = real_us > 0
-        return round(float((whole[ok] / real_us[ok]).mean() / 1e3), 3) if ok.any() else None
+        if not ok.any():
+            return None
+        # GHz, and what it is the quotient of: shader cycles and real microseconds between kernel entry and "slab written", mean over
+        # workgroups, of the STAMPED instantiation (a few per cent slower than the product: the stamps)
+        return {"ghz": round(float((whole[ok] / real_us[ok]).mean() / 1e3), 3), "cycles": round(float(whole[ok].mean())),
+                "real_us": round(float(real_us[ok].mean()), 2)}
     except Exception:       # noqa: BLE001  (a diagnostic: never cost the line)
         return None
 
@@ -479,7 +484,8 @@ def kernel_rooflines(num_envs, T, reps, gemm="f32"):
         ks.insert(0, mfma("%s (forward + loss + dX + dW, %d rows; + %s)" % (fused_kernel[0], rows, fused_kernel[1]), t_fused,
                           (MLP_FWD_FLOP + MLP_BWD_DX_FLOP + MLP_GRAD_W_FLOP) * rows, 75, peak=mlp_peak_for("f16x2" if h2 else pol.gemm)))
         ks[0]["arithmetic"] = "f16x2" if h2 else pol.gemm
-        ks[0]["in_kernel_clock_ghz"] = fused_clock
+        ks[0]["in_kernel_clock_ghz"] = fused_clock["ghz"] if fused_clock else None
+        ks[0]["in_kernel_clock_source"] = fused_clock
     # the env kernel's REAL bound is vector-instruction issue, not HBM: instructions per wave (committed PMC pass,
     # profiles/*_valu.json) x 4 issue cycles at one wave per SIMD, against the measured launch
     try:
