@@ -56,6 +56,8 @@ def parse():
                     help="ppo (default, BASELINE's metric config) or dqn = BASELINE configs[4] (labelled line of its own)")
     ap.add_argument("--dqn_envs", type=int, default=32768)
     ap.add_argument("--dqn_mini_batch", type=int, default=128, help="sampled replay steps per update (dqn.py:49)")
+    ap.add_argument("--dqn_gemm", choices=["f16x2", "bf16x3"], default=None,
+                    help="arithmetic of the fused DQN update (default: FLY_DQN_GEMM or f16x2; bf16x3 = round 4's launches, the A/B)")
     ap.add_argument("--dry_run", action="store_true",
                     help="rank plumbing only (spawn, rendezvous, barrier, max-over-ranks timing, the JSON line) with no "
                          "GPU work: what the CPU/gloo test of --gpus N exercises")
@@ -701,7 +703,7 @@ DQN_FWD_FLOP = 2 * (73 * 256 + 256 * 256 + 256 * 18)            # 177 664 per sa
 DQN_BWD_DX_FLOP = 2 * (18 * 256 + 256 * 256)                     # 140 288
 
 
-def dqn_measure(n, mb, warmup, steps, kernel_reps):
+def dqn_measure(n, mb, warmup, steps, kernel_reps, gemm=None):
     """BASELINE configs[4]: DQN, 32768 envs, HBM-resident replay ring (stated capacity), per-env eps-greedy and
     Huber-TD on the HIP kernels.  A "step" = one DQN.run(): act (one launch), env step, record into the ring,
     one update on `dqn_mini_batch` sampled steps x num_envs rows (dqn.py:102-126).  One rank (the reference DQN
@@ -713,7 +715,7 @@ def dqn_measure(n, mb, warmup, steps, kernel_reps):
     torch.manual_seed(0)
     cap = max(4 * mb, 64)
     with quiet():
-        agent = DQN(make_args(n, dqn_mini_batch_size=mb, replay_steps=cap))
+        agent = DQN(make_args(n, dqn_mini_batch_size=mb, replay_steps=cap, dqn_gemm=gemm))
         for _ in range(mb + warmup):                # fill the ring to the sample size (no updates yet), then `warmup` steps with updates
             agent.run()
     torch.cuda.synchronize()
@@ -724,6 +726,7 @@ def dqn_measure(n, mb, warmup, steps, kernel_reps):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     assert int(agent.packed.step.item()) == warmup + steps, "an update was skipped"
+    h2_refused = int(agent.h2_overflows)
     finite = all(torch.isfinite(p).all().item() for p in agent.q.parameters())
     lib = _lib.load()
     p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
@@ -748,25 +751,39 @@ def dqn_measure(n, mb, warmup, steps, kernel_reps):
         t = {}
         agent._update_fused(chunks, inv_B)                                   # sizes the buffers
         dev, aligned = agent._fused_table(chunks)
+        h2 = agent.update_gemm == "f16x2"
+        agent.h2_freeze = True                                               # (timing launches: leave the scales where the run left them)
+        launch = (lambda: agent._fused_launch_h2(dev, mb, n, aligned, inv_B, 1)) if h2 else (lambda: agent._fused_launch(dev, mb, n, aligned, inv_B))
+        t_extra = 0.0
+        if h2:      # the two small kernels every fp16x2 update adds (weight planes + weight scales in front, next scales behind)
+            lib.flyhip_debug_set_dqn_fused_phases(0)
+            t_extra = _time_launches(launch, 20)
         for name, mask in (("chain", 1), ("dw2", 2), ("reduce", 4)):
             lib.flyhip_debug_set_dqn_fused_phases(mask)
-            t[name] = _time_launches(lambda: agent._fused_launch(dev, mb, n, aligned, inv_B), 3 if mask < 4 else 20)
+            t[name] = _time_launches(launch, 3 if mask < 4 else 20) - t_extra
         lib.flyhip_debug_set_dqn_fused_phases(7)
-        peak = mlp_peak_for("bf16x3")
+        agent.packed.h2_overflow.zero_()
+        peak = mlp_peak_for("f16x2" if h2 else "bf16x3")
+        kn = ("dqn_chain_h2_kernel", "dqn_dw2_h2_kernel") if h2 else ("dqn_chain_kernel", "dqn_dw2_kernel")
         rows = n * mb
         dw13 = 2 * (73 * 256 + 256 * 18)                                   # dW1 + dW3 per row
-        ks = [mfma("dqn_chain_kernel (per 32-row tile: target fwd, online fwd, Huber-TD, dX chain, dW1 / dW3 / db in registers; "
-                   "%d rows = one update)" % rows, t["chain"], (2 * DQN_FWD_FLOP + DQN_BWD_DX_FLOP + dw13) * rows, 1, peak),
-              mfma("dqn_dw2_kernel (dW2 over the saved H1 | dZ2 plane images)", t["dw2"], 2 * 256 * 256 * rows, 1, peak),
+        ks = [mfma(kn[0] + " (per 32-row tile: target fwd, online fwd, Huber-TD, dX chain, dW1 / dW3 / db in registers; "
+                   "%d rows = one update%s)" % (rows, "; with dqn_h2_scales_kernel behind it" if h2 else ""),
+                   t["chain"], (2 * DQN_FWD_FLOP + DQN_BWD_DX_FLOP + dw13) * rows, 1, peak),
+              mfma(kn[1] + " (dW2 over the saved H1 | dZ2 plane images)", t["dw2"], 2 * 256 * 256 * rows, 1, peak),
               {"kernel": "dqn_grad_reduce_kernel (fixed-order sum of the per-CU slabs)", "avg_launch_us": round(t["reduce"] * 1e6, 3),
                "launches_per_step": 1, "step_share_ms": round(t["reduce"] * 1e3, 3)},
               mfma("dqn_act_kernel (forward + argmax + eps-greedy)", t_act, DQN_FWD_FLOP * n, 1)]
-        dtype = "bf16x3"
+        dtype = "f16x2" if h2 else "bf16x3"
+        if h2:
+            ks.insert(3, {"kernel": "dqn_h2_planes_kernel (per update: two-term weight planes and weight scales of both networks)",
+                          "avg_launch_us": round(t_extra * 1e6, 3),
+                          "launches_per_step": 1, "step_share_ms": round(t_extra * 1e3, 3)})
         # HBM bytes from the committed PMC passes (profiles/*_traffic.json: per launch of PROF_DQN_MB sampled steps -> scaled to `mb`)
         try:
             files = [f for f in [latest_profile("*_traffic.json")] if f]
             tr = json.load(open(files[-1])) if files else {}
-            for k, nm in ((ks[0], "dqn_chain_kernel"), (ks[1], "dqn_dw2_kernel")):
+            for k, nm in ((ks[0], kn[0]), (ks[1], kn[1])):
                 t = next((v for kk, v in sorted(tr.items()) if kk.startswith(nm + "@") and "hbm_bytes_per_sampled_step" in v), None)
                 if t and n == 32768:
                     k["traffic"] = t["hbm_bytes_per_sampled_step"] * mb
@@ -795,7 +812,9 @@ def dqn_measure(n, mb, warmup, steps, kernel_reps):
         "metric": "env-steps/sec (DQN act + env step + update), %d envs" % n, "value": round(n * steps / elapsed, 1),
         "unit": "env-steps/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-        "update_path": "dqn_fused_update (bf16x3 chain + dW2 over plane images)" if fused else "dqn_td_step + dqn_grad_w per sampled step (fp32 MFMA)",
+        "update_path": (("dqn_fused_update_h2 (fp16x2 chain + dW2 over two-plane images; %d of the run's updates refused and formed again in bf16x3)"
+                         % h2_refused) if dtype == "f16x2" else "dqn_fused_update (bf16x3 chain + dW2 over plane images)") if fused
+                       else "dqn_td_step + dqn_grad_w per sampled step (fp32 MFMA)",
         "config": {"workload": "fly_dqn_%denvs_batch%dsteps" % (n, mb), "num_envs_per_gpu": n, "sampled_steps_per_update": mb,
                    "rows_per_update": n * mb, "replay_capacity_steps": capacity, "replay_bytes": rbytes,
                    "updates_per_env_step": 1, "parallelism": "dp1"},
@@ -805,7 +824,7 @@ def dqn_measure(n, mb, warmup, steps, kernel_reps):
 def dqn_bench(a):
     if a.gpus != 1:
         sys.exit("bench.py --workload dqn runs on one GPU")
-    print(json.dumps(dqn_measure(a.dqn_envs, a.dqn_mini_batch, a.warmup, a.steps, a.kernel_reps)), flush=True)
+    print(json.dumps(dqn_measure(a.dqn_envs, a.dqn_mini_batch, a.warmup, a.steps, a.kernel_reps, a.dqn_gemm)), flush=True)
 
 
 GEMM_LABEL = {
@@ -1037,9 +1056,9 @@ def main():
         line["kernels"] = ks[1:]
         if world == 1 and not a.no_dqn:
             try:        # BASELINE configs[4], short and labelled: 32768 envs, stated ring, 10 timed env steps (after 2) with one update each
-                d = dqn_measure(a.dqn_envs, a.dqn_mini_batch, 2, 10, max(5, a.kernel_reps // 4))
-                line["dqn"] = {k: d[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config",
-                                                 "params_finite", "roofline")}
+                d = dqn_measure(a.dqn_envs, a.dqn_mini_batch, 2, 10, max(5, a.kernel_reps // 4), a.dqn_gemm)
+                line["dqn"] = {k: d[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "update_path",
+                                                 "config", "params_finite", "roofline")}
             except Exception as e:      # noqa: BLE001
                 line["dqn"] = {"error": repr(e)[:200]}
         if world == 1 and not a.no_cpu_baseline:

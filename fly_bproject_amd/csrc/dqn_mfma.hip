@@ -25,6 +25,8 @@ namespace {
 #include "grad_w_layer.inc"
 #include "fs_common.inc"
 #include "dqn_fused.inc"
+#include "fs_h2.inc"
+#include "dqn_fused_h2.inc"
 
 constexpr int DQ_P = DQN_H + 4;                         // LDS pitch of a [32][256] activation tile
 constexpr int DQ_TILE = BM * DQ_P;                      // 8320 floats
@@ -550,4 +552,70 @@ extern "C" hipError_t flyhip_launch_dqn_fused_update(const float* P, const uint1
     T.l[3] = T.l[2];
     hipLaunchKernelGGL(dqn_grad_reduce_kernel, dim3(DQ_RED_BLOCKS), dim3(64 * DQ_RED_WAVES), 0, (hipStream_t)stream, T, grad, 0);
     return hipGetLastError();
+}
+
+// ---- the same update in the fp16x2 arithmetic (dqn_fused_h2.inc): weight planes + scales, chain, dW2, slab reduction, next scales -----
+extern "C" int64_t flyhip_dqn_fused_h2_workspace_floats(void) { return (int64_t)dqn_cus() * (DQN_PACKED_FLOATS + H2_NACT_CLASSES); }
+extern "C" int64_t flyhip_dqn_fused_h2_image_halves(int64_t rows) { return (rows / BM) * 2 * (int64_t)DH_IMAGE_HALVES; }
+
+// flags: bit 0 = leave the lagged scales as they are (tests: run-to-run comparisons), bit 1 = calibration pass (no dW2, no
+// reduction: only the class maxima -> scales; `grad` is not written)
+extern "C" hipError_t flyhip_launch_dqn_fused_update_h2(const float* P, uint16_t* QH, uint16_t* QTH, const float* P_tgt, uint16_t* QH_tgt,
+                                                        const int* idx_fb, const int* idx_tb, float* fsc, int* ovf, const void* chunks,
+                                                        int S, int64_t n, float discount, float inv_B, uint16_t* images, float* workspace,
+                                                        float* grad, float* loss_part, int rows_aligned16, int flags, void* stream)
+{
+    const long tiles_per = n / BM, ntiles = (long)S * tiles_per;
+    if (ntiles <= 0 || ntiles + 4096 >= (1L << 31)) return hipErrorInvalidValue;
+    const int cus = dqn_cus();
+    const int grid = (int)(ntiles < cus ? ntiles : cus);
+    {
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(dqn_chain_h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            DH_LDS_BYTES);
+        if (ea != hipSuccess) return ea;
+        ea = hipFuncSetAttribute(reinterpret_cast<const void*>(dqn_dw2_h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW2H_LDS_BYTES);
+        if (ea != hipSuccess) return ea;
+    }
+    float* ws1 = workspace;
+    float* ws2 = ws1 + (long)cus * DF_STRIDE1;
+    float* ws3 = ws2 + (long)cus * DF_STRIDE2;
+    float* wsmax = ws3 + (long)cus * DF_STRIDE3;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(dqn_h2_planes_kernel, dim3(DH_PL_BLOCKS), dim3(DH_PL_THREADS), 0, st, P, P_tgt, idx_fb, idx_tb, QH, QTH, QH_tgt, fsc);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (g_dqn_phases & 1) {
+        hipLaunchKernelGGL(dqn_chain_h2_kernel, dim3(grid), dim3(THREADS), DH_LDS_BYTES, st, P, QH, QTH, P_tgt, QH_tgt, fsc,
+                           static_cast<const DqnChunk*>(chunks), S, tiles_per, discount, inv_B, images, ws1, ws2, ws3, wsmax, loss_part,
+                           g_dqn_stamps, rows_aligned16);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (!(flags & 2)) {
+        if (g_dqn_phases & 2) {
+            hipLaunchKernelGGL(dqn_dw2_h2_kernel, dim3(grid), dim3(THREADS), DW2H_LDS_BYTES, st, images, ntiles, fsc, ws2);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+        if (g_dqn_phases & 4) {
+            GradWTable T;
+            float* part[3] = {ws1, ws2, ws3};
+            const int N[3] = {DQN_H, DQN_H, DQN_OUT};
+            const int KP[3] = {DQN_IN_PAD, DQN_H, DQN_H};
+            for (int l = 0; l < 3; ++l) {
+                T.l[l].dz = nullptr; T.l[l].a = nullptr; T.l[l].partial = part[l];
+                T.l[l].N = N[l]; T.l[l].Ka = KP[l]; T.l[l].KP = KP[l]; T.l[l].wgs = grid; T.l[l].first_block = 0; T.l[l].accumulate = 0;
+                T.l[l].chunked = 0;
+            }
+            T.l[3] = T.l[2];
+            hipLaunchKernelGGL(dqn_grad_reduce_kernel, dim3(DQ_RED_BLOCKS), dim3(64 * DQ_RED_WAVES), 0, st, T, grad, 0);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+    }
+    if (g_dqn_phases & 1) {
+        hipLaunchKernelGGL(dqn_h2_scales_kernel, dim3(1), dim3(64 * DH_NMAX), 0, st, wsmax, grid, fsc, ovf, flags & 1);
+        e = hipGetLastError();
+    }
+    return e;
 }

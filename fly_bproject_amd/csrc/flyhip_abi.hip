@@ -175,7 +175,7 @@ int launch(FlyHandle h, int phases, const float* actions, const FlyBuffers* b, v
 extern "C" {
 
 const char* fly_last_error(void) { return g_err; }
-int fly_abi_version(void) { return 10; }
+int fly_abi_version(void) { return 11; }
 
 int fly_create(const FlyConfig* cfg, FlyHandle* out)
 {
@@ -632,6 +632,35 @@ int dqn_fused_update(const float* params, const uint16_t* params_b3, const uint1
     hipError_t e = flyhip_launch_dqn_fused_update(params, params_b3, params_t_b3, target_params, target_params_b3, chunks, num_chunks, n,
                                                   discount, inv_B, images, workspace, grad, loss_part, rows_aligned16 ? 1 : 0, stream);
     if (e != hipSuccess) return hip_fail(e, "dqn_fused_update launch");
+    return FLY_OK;
+}
+
+extern "C" int64_t flyhip_dqn_fused_h2_workspace_floats(void);
+extern "C" int64_t flyhip_dqn_fused_h2_image_halves(int64_t rows);
+extern "C" hipError_t flyhip_launch_dqn_fused_update_h2(const float* P, uint16_t* QH, uint16_t* QTH, const float* P_tgt, uint16_t* QH_tgt,
+                                                        const int* idx_fb, const int* idx_tb, float* fsc, int* ovf, const void* chunks,
+                                                        int S, int64_t n, float discount, float inv_B, uint16_t* images, float* workspace,
+                                                        float* grad, float* loss_part, int rows_aligned16, int flags, void* stream);
+
+int64_t dqn_fused_h2_workspace_floats(void) { return flyhip_dqn_fused_h2_workspace_floats(); }
+int64_t dqn_fused_h2_image_halves(int64_t rows) { return flyhip_dqn_fused_h2_image_halves(rows); }
+
+int dqn_fused_update_h2(const float* params, uint16_t* params_h2, uint16_t* params_t_h2, const float* target_params,
+                        uint16_t* target_params_h2, const int32_t* idx_b3, const int32_t* idx_t_b3, float* h2_scales,
+                        int32_t* h2_overflow, const void* chunks, int32_t num_chunks, int64_t n, float discount, float inv_B,
+                        uint16_t* images, float* workspace, float* grad, float* loss_part, int32_t rows_aligned16, int32_t flags,
+                        void* stream)
+{
+    if (!params || !params_h2 || !params_t_h2 || !target_params || !target_params_h2 || !idx_b3 || !idx_t_b3 || !h2_scales ||
+        !h2_overflow || !chunks || !images || !workspace || !grad || !loss_part)
+        return fail(FLY_E_ARG, "dqn_fused_update_h2: null pointer");
+    if (num_chunks <= 0 || n <= 0 || (n % 32) != 0)
+        return fail(FLY_E_ARG, "dqn_fused_update_h2: needs num_chunks > 0 and n a positive multiple of 32 (whole tiles; use dqn_td_step + dqn_grad_w otherwise)");
+    if (!(inv_B > 0.0f) || !(inv_B < 1.0e30f)) return fail(FLY_E_ARG, "dqn_fused_update_h2: inv_B must be a positive finite number");
+    hipError_t e = flyhip_launch_dqn_fused_update_h2(params, params_h2, params_t_h2, target_params, target_params_h2, idx_b3, idx_t_b3,
+                                                     h2_scales, h2_overflow, chunks, num_chunks, n, discount, inv_B, images, workspace, grad,
+                                                     loss_part, rows_aligned16 ? 1 : 0, flags & 3, stream);
+    if (e != hipSuccess) return hip_fail(e, "dqn_fused_update_h2 launch");
     return FLY_OK;
 }
 

@@ -68,6 +68,8 @@ def build_index_maps():
 
 
 QB_HALVES = 3 * (H * IN_PAD + H * H + OUT * H)      # 282624 (csrc/dqn_layout.h)
+QH_HALVES = 2 * (H * IN_PAD + H * H + OUT * H)      # 188416: two fp16 terms per weight (csrc/dqn_fused_h2.inc)
+QTH_HALVES = 2 * (H * OUT + H * H)                  # 147456
 QTB_HALVES = 3 * (H * OUT + H * H)                  # 221184
 OFF_QB = (0, 3 * H * IN_PAD, 3 * (H * IN_PAD + H * H))
 OFF_QTB3, OFF_QTB2 = 0, 3 * H * OUT
@@ -210,6 +212,12 @@ class QNetPacked:
         self.idx_tb = torch.from_numpy(idx_tb).to(self.device)
         self._src_fb = torch.nonzero(self.idx_fb >= 0).squeeze(-1); self._dst_fb = self.idx_fb[self._src_fb].long()
         self._src_tb = torch.nonzero(self.idx_tb >= 0).squeeze(-1); self._dst_tb = self.idx_tb[self._src_tb].long()
+        # the fp16x2 update (csrc/dqn_fused_h2.inc): two-term weight planes (rebuilt by every `dqn_fused_update_h2` call from the masters),
+        # the scale table (s | 1 / s | last maxima: 48 floats) and the overflow word
+        self.QH, self.QTH, self.QH_tgt = zi(QH_HALVES), zi(QTH_HALVES), zi(QH_HALVES)
+        self.h2_scales = z(48)
+        self.h2_scales[:32] = 1.0
+        self.h2_overflow = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.refresh()
 
     def refresh(self):
@@ -263,6 +271,15 @@ class DQN:
         import os
         want = getattr(args, "dqn_fused", None)
         self.fused_update = (os.environ.get("FLY_DQN_FUSED", "1") != "0") if want is None else bool(want)
+        # the fused update's arithmetic: "f16x2" (two fp16 terms per operand, three MFMA products per k block, per-class power-of-two
+        # scales: csrc/dqn_fused_h2.inc; an update whose values did not fit is formed again in bf16x3) or "bf16x3" (csrc/dqn_fused.inc)
+        gemm = getattr(args, "dqn_gemm", None) or os.environ.get("FLY_DQN_GEMM", "f16x2")
+        if gemm not in ("f16x2", "bf16x3"):
+            raise ValueError("dqn_gemm / FLY_DQN_GEMM must be f16x2 or bf16x3, not %r" % (gemm,))
+        self.update_gemm = gemm
+        self.h2_calibrated = False          # the lagged scales have seen an update's maxima
+        self.h2_freeze = False              # tests: leave the lagged scales alone (run-to-run comparisons)
+        self.h2_overflows = 0               # updates whose fp16x2 gradient was refused and formed again in bf16x3
         self._gen = torch.Generator(device=dev)
         self._gen.manual_seed(int(getattr(args, "seed", 0)))
         self._coin = torch.empty(n, device=dev)
@@ -290,8 +307,9 @@ class DQN:
         tiles = S * n // 32
         if getattr(self, "_fu_rows", 0) < S * n:
             self._fu_rows = S * n
+            # (sized for the bf16x3 launches -- the larger images -- and the fp16x2 workspace -- the larger workspace: either can run)
             self._fu_images = torch.empty(int(lib.dqn_fused_image_halves(C.c_int64(S * n))), dtype=torch.int16, device=self.device)
-            self._fu_ws = torch.empty(int(lib.dqn_fused_workspace_floats()), device=self.device)
+            self._fu_ws = torch.empty(max(int(lib.dqn_fused_workspace_floats()), int(lib.dqn_fused_h2_workspace_floats())), device=self.device)
             self._fu_loss = torch.zeros(tiles, device=self.device)
         if getattr(self, "_fu_S", 0) < S:
             # the chunk tables have a capacity of their own: an update of MORE chunks over no more rows (8 x 4096 after 4 x 8192)
@@ -303,6 +321,21 @@ class DQN:
                              [None]) for _ in range(4)]
             self._fu_i = 0
         dev, aligned = self._fused_table(chunks)
+        if self.update_gemm == "f16x2":
+            if not self.h2_calibrated:
+                # two passes over this update's rows that only take the class maxima (the second with the first's scales)
+                for _ in range(2):
+                    self._fused_launch_h2(dev, S, n, aligned, inv_B, 2)
+                pk.h2_overflow.zero_()
+                self.h2_calibrated = True
+            loss_part = self._fused_launch_h2(dev, S, n, aligned, inv_B, 1 if self.h2_freeze else 0)
+            if int(pk.h2_overflow.item()) == 0:          # (a blocking read per update: ~15 ms of launches)
+                return loss_part
+            # some value did not fit fp16 under the scales the previous update left: nothing has been applied yet -- the bf16x3
+            # launches form the same gradient with no scales at all, and the next update calibrates again
+            pk.h2_overflow.zero_()
+            self.h2_overflows += 1
+            self.h2_calibrated = False
         return self._fused_launch(dev, S, n, aligned, inv_B)
 
     def _fused_table(self, chunks):
@@ -331,6 +364,16 @@ class DQN:
         _lib.check(lib.dqn_fused_update(p(pk.P), p(pk.QB), p(pk.QTB), p(pk.P_tgt), p(pk.QB_tgt), p(dev), C.c_int(S), C.c_int64(n),
                                         C.c_float(self.discount), C.c_float(inv_B), p(self._fu_images), p(self._fu_ws), p(pk.G),
                                         p(loss_part), C.c_int(aligned), _lib.stream_ptr()), "dqn_fused_update")
+        return loss_part
+
+    def _fused_launch_h2(self, dev, S, n, aligned, inv_B, flags):
+        pk, lib = self.packed, self._lib
+        p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+        loss_part = self._fu_loss[:S * n // 32]
+        _lib.check(lib.dqn_fused_update_h2(p(pk.P), p(pk.QH), p(pk.QTH), p(pk.P_tgt), p(pk.QH_tgt), p(pk.idx_fb), p(pk.idx_tb),
+                                           p(pk.h2_scales), p(pk.h2_overflow), p(dev), C.c_int(S), C.c_int64(n), C.c_float(self.discount),
+                                           C.c_float(inv_B), p(self._fu_images), p(self._fu_ws), p(pk.G), p(loss_part), C.c_int(aligned),
+                                           C.c_int(flags), _lib.stream_ptr()), "dqn_fused_update_h2")
         return loss_part
 
     def update(self, chunks=None):

@@ -486,6 +486,27 @@ int dqn_fused_update(const float* params, const uint16_t* params_b3, const uint1
                      const uint16_t* target_params_b3, const void* chunks, int32_t num_chunks, int64_t n, float discount,
                      float inv_B, uint16_t* images, float* workspace, float* grad, float* loss_part,
                      int32_t rows_aligned16, void* stream);
+/* The same gradient in the fp16x2 arithmetic of mlp_fused_grad_h2 (fly_bproject_amd/csrc/dqn_fused_h2.inc): two fp16 terms per GEMM
+ * operand, three MFMA products per k block, two-plane images (64 KB per tile).  ONE call = weight planes + weight scales from the
+ * CURRENT params / target_params (params_h2 DQN_QH_HALVES_ABI, params_t_h2 DQN_QTH_HALVES_ABI, target_params_h2 DQN_QH_HALVES_ABI
+ * 16-bit words: scratch the library owns the contents of; idx_b3 / idx_t_b3 = dqn_adam_soft_update's plane maps), the two persistent
+ * launches, the slab reduction, and the NEXT call's activation / gradient scales from this call's class maxima.
+ *   h2_scales    device float [MLP_H2_SCALE_FLOATS_ABI]: s[c] at [c], 1 / s[c] at [16 + c], the last call's maximum of |scaled value|
+ *                at [32 + c]; classes 0 X, 1 H1, 2 H2, 5 dZ2, 6 dZ1 (lagged), 8 .. 10 / 11 .. 13 online / target W1 .. W3 (exact, per
+ *                call).  Start it at 1.0 / 1.0 / 0 and run two calls with flags = 2 on the first update's chunks.
+ *   h2_overflow  device int: set to 1 when a value of THIS call did not fit fp16 under the lagged scales -- `grad` is then invalid:
+ *                clear the word, form the gradient with dqn_fused_update (bf16x3; nothing has been applied yet) and calibrate again.
+ *   flags        bit 0: leave the lagged scales unchanged; bit 1: calibration pass (class maxima -> scales only; `grad` not written).
+ * `workspace`: dqn_fused_h2_workspace_floats() floats; `images`: dqn_fused_h2_image_halves(num_chunks * n) 16-bit words. */
+#define DQN_QH_HALVES_ABI 188416
+#define DQN_QTH_HALVES_ABI 147456
+int64_t dqn_fused_h2_workspace_floats(void);
+int64_t dqn_fused_h2_image_halves(int64_t rows);
+int dqn_fused_update_h2(const float* params, uint16_t* params_h2, uint16_t* params_t_h2, const float* target_params,
+                        uint16_t* target_params_h2, const int32_t* idx_b3, const int32_t* idx_t_b3, float* h2_scales,
+                        int32_t* h2_overflow, const void* chunks, int32_t num_chunks, int64_t n, float discount, float inv_B,
+                        uint16_t* images, float* workspace, float* grad, float* loss_part, int32_t rows_aligned16, int32_t flags,
+                        void* stream);
 int dqn_adam_soft_update(float* params, float* params_frag, float* params_t_frag, float* target_params,
                          float* target_params_frag, const int32_t* idx_frag, const int32_t* idx_t_frag,
                          const float* grad, const float* mask, float* exp_avg, float* exp_avg_sq, int32_t* step,

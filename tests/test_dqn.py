@@ -63,8 +63,9 @@ def test_hip_huber_td_vs_reference_and_oracle(golden):
     np.testing.assert_allclose(dq.cpu().numpy(), dq2, rtol=3e-7, atol=0)     # d/B vs d*(1/B): one ulp
 
 
-def _bare_dqn(golden_sd=None, rows=384, fused=False):
-    """A DQN without an environment: the packed Q-network pair + workspace on cuda:0."""
+def _bare_dqn(golden_sd=None, rows=384, fused=False, gemm="f16x2"):
+    """A DQN without an environment: the packed Q-network pair + workspace on cuda:0.  `gemm`: the fused update's arithmetic
+    (f16x2, the default of DQN, or bf16x3)."""
     from fly_bproject_amd import _lib
     from fly_bproject_amd.dqn import DQN, Net, QNetPacked, soft_update
     d = DQN.__new__(DQN)
@@ -78,6 +79,7 @@ def _bare_dqn(golden_sd=None, rows=384, fused=False):
     d.packed = QNetPacked(d.q, d.q_target, "cuda:0")
     d._alloc_workspace(rows)
     d.fused_update = fused
+    d.update_gemm, d.h2_calibrated, d.h2_freeze, d.h2_overflows = gemm, False, False, 0
     return d
 
 
@@ -131,7 +133,7 @@ def test_fused_act_equals_forward_plus_eps_greedy(golden, eps):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [False, "bf16x3", "f16x2"])
 def test_dqn_update_matches_reference_step(golden, fused):
     """One DQN.update from the reference's weights on the reference's batch, all on the HIP kernels
     (dqn_td_step + dqn_grad_w + dqn_adam_soft_update): same loss, same Q-network and target network
@@ -142,7 +144,7 @@ def test_dqn_update_matches_reference_step(golden, fused):
     B = batch[0].shape[0]
     assert B % 128 == 0                      # whole 32-row tiles in four chunks too: the fused launches take both splits
     for parts in (1, 4):
-        d = _bare_dqn({k[2:]: t(g[k]) for k in g.files if k.startswith("q_") and "." in k}, fused=fused)
+        d = _bare_dqn({k[2:]: t(g[k]) for k in g.files if k.startswith("q_") and "." in k}, fused=bool(fused), gemm=fused or "f16x2")
         step = B // parts
         chunks = [tuple(x[i * step:(i + 1) * step].contiguous() for x in batch) for i in range(parts)]
         loss = d.update(chunks)
@@ -160,16 +162,17 @@ def test_dqn_update_matches_reference_step(golden, fused):
         d.packed.refresh()
         assert torch.equal(pf, d.packed.PF) and torch.equal(pt, d.packed.PT) and torch.equal(pft, d.packed.PF_tgt)
         assert torch.equal(qb, d.packed.QB) and torch.equal(qtb, d.packed.QTB) and torch.equal(qbt, d.packed.QB_tgt)   # the bf16x3 planes too
+        assert d.h2_overflows == 0 and d.h2_calibrated == (fused == "f16x2")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused,B", [(False, 1000), (True, 1024), (True, 16384)])
+@pytest.mark.parametrize("fused,B", [(False, 1000), ("bf16x3", 1024), ("bf16x3", 16384), ("f16x2", 1024), ("f16x2", 16384)])
 def test_dqn_td_gradient_matches_autograd(fused, B):
     """The packed gradient of one update batch (TD target from the target net, Huber, backward, dW) against
     torch autograd on the same module in fp64-free fp32; random weights; 1000 rows (ragged tile) through the per-step
-    launches, whole tiles through the fused bf16x3 launches (16384 rows: every workgroup walks two tiles)."""
+    launches, whole tiles through the fused launches in both arithmetics (16384 rows: every workgroup walks two tiles)."""
     torch.manual_seed(5)
-    d = _bare_dqn(rows=B, fused=fused)
+    d = _bare_dqn(rows=B, fused=bool(fused), gemm=fused or "f16x2")
     with torch.no_grad():
         for p_ in d.q_target.parameters():
             p_.add_(0.05 * torch.randn_like(p_))                 # target differs from online
@@ -197,18 +200,20 @@ def test_dqn_td_gradient_matches_autograd(fused, B):
         scale = float(want.abs().max()) + 1e-12
         assert float((got - want).abs().max()) <= 2e-4 * scale + 1e-9, name
     assert not torch.equal(before, d.packed.P)
+    assert d.h2_overflows == 0
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("gemm", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("parts,n,skew", [(5, 4096, 0), (5, 4096, 1), (3, 96, 1), (1, 32, 0)])
-def test_dqn_fused_update_over_chunks_and_misaligned_rows(parts, n, skew):
+def test_dqn_fused_update_over_chunks_and_misaligned_rows(parts, n, skew, gemm):
     """dqn_fused_update on several sampled steps: 5 x 4096 rows = 640 tiles, so workgroups walk up to three tiles across chunk
     boundaries (rows and scalars of the NEXT tile are requested a tile ahead); `skew` = 1 puts every row block one row into its
     allocation (292 bytes: not 16-byte aligned), which takes the plain-load path instead of LDS-DMA; 32 rows = one tile, one
     workgroup.  Against torch autograd on the concatenated batch."""
     torch.manual_seed(11)
     B = parts * n
-    d = _bare_dqn(rows=B, fused=True)
+    d = _bare_dqn(rows=B, fused=True, gemm=gemm)
     with torch.no_grad():
         for p_ in d.q_target.parameters():
             p_.add_(0.05 * torch.randn_like(p_))
@@ -237,17 +242,19 @@ def test_dqn_fused_update_over_chunks_and_misaligned_rows(parts, n, skew):
     for (name, _), want in zip(d.q.named_parameters(), grads):
         scale = float(want.abs().max()) + 1e-12
         assert float((views[name] - want).abs().max()) <= 2e-4 * scale + 1e-9, name
+    assert d.h2_overflows == 0
 
 
 @pytest.mark.gpu
-def test_dqn_fused_update_at_full_size_is_deterministic_and_linear():
+@pytest.mark.parametrize("gemm", ["bf16x3", "f16x2"])
+def test_dqn_fused_update_at_full_size_is_deterministic_and_linear(gemm):
     """BASELINE configs[4]'s row count per sampled step (32768), eight sampled steps: (i) two runs on the same inputs leave the same
     packed gradient and per-tile loss sums bit for bit (fixed-order reductions everywhere: no atomics); (ii) the gradient of the batch
     is the mean of the gradients of its halves (the update is a sum over rows scaled by 1 / B: any row lost or doubled at a tile,
     chunk or workgroup boundary breaks this), to summation-order rounding; (iii) it agrees with the per-step fp32-MFMA launches."""
     torch.manual_seed(3)
     n, parts = 32768, 8
-    d = _bare_dqn(rows=n, fused=True)
+    d = _bare_dqn(rows=n, fused=True, gemm=gemm)
     with torch.no_grad():
         for p_ in d.q_target.parameters():
             p_.add_(0.05 * torch.randn_like(p_))
@@ -267,9 +274,12 @@ def test_dqn_fused_update_at_full_size_is_deterministic_and_linear():
         loss = d.update(cs)
         torch.cuda.synchronize()
         return d.packed.G.clone(), float(loss)
+    if gemm == "f16x2":     # the first update calibrates the lagged scales; from there on they stay as they are (they are a launch's INPUT:
+        grad(chunks)        # two launches with different scales differ in rounding, two with the same scales must not differ at all)
+        d.h2_freeze = True
     g1, l1 = grad(chunks)
     g2, l2 = grad(chunks)
-    assert torch.equal(g1, g2) and l1 == l2
+    assert torch.equal(g1, g2) and l1 == l2 and d.h2_overflows == 0
     ga, la = grad(chunks[:parts // 2])
     gb, lb = grad(chunks[parts // 2:])
     m = d.packed.grad_mask > 0

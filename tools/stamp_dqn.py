@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-phase shader cycles of dqn_chain_kernel (the second tile of every workgroup, thread 0) and HIP-event times of one fused DQN
-update at 32768 envs x S sampled steps: stamp_dqn.py [S]"""
+update at 32768 envs x S sampled steps: stamp_dqn.py [S] [f16x2 (default: dqn_chain_h2_kernel, coarse phases only) | bf16x3]"""
 import contextlib
 import ctypes as C
 import io
@@ -16,9 +16,10 @@ from fly_bproject_amd import _lib  # noqa: E402
 from fly_bproject_amd.dqn import DQN  # noqa: E402
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+gemm = sys.argv[2] if len(sys.argv) > 2 else "f16x2"
 n = 32768
 with contextlib.redirect_stdout(io.StringIO()):
-    agent = DQN(make_args(n, dqn_mini_batch_size=S, replay_steps=max(2 * S, 8)))
+    agent = DQN(make_args(n, dqn_mini_batch_size=S, replay_steps=max(2 * S, 8), dqn_gemm=gemm))
     for _ in range(S + 2):
         agent.run()
 torch.cuda.synchronize()
@@ -40,9 +41,12 @@ names = ["target: input planes", "target L1", "target L2", "target L3 + partials
          "online L1", "online L2", "online L3 + partials", "loss + dZ3", "dA2, dZ2, dW3, db", "dA1, dZ1, dW1", "image copy-out", ]
 d = np.diff(s[:, :14], axis=1).astype(np.float64)
 ok = (s[:, 13] > 0)
-print("workgroups stamped: %d; cycles per tile %.0f" % (ok.sum(), d[ok].sum(1).mean()))
+print("%s: workgroups stamped: %d; cycles per tile %.0f; updates refused: %d" % (gemm, ok.sum(), d[ok].sum(1).mean(), agent.h2_overflows))
 for i, nm in enumerate(names):
     print("  %-30s %8.0f" % (nm, d[ok][:, i].mean()))
+if gemm != "bf16x3":
+    agent.exit()
+    sys.exit(0)
 fine = ["L1 GEMM a", "L1 GEMM b (+ L1 epilogue a)", "barrier", "L2 GEMM a (+ L1 epilogue b, barrier inside)", "L2 GEMM b (+ L2 epilogue a)",
         "head requests", "L3 GEMM (+ L2 epilogue b)", "partials + barrier"]
 for ps, (base, c0) in enumerate(((16, 1), (32, 6))):
