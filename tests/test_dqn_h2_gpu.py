@@ -39,9 +39,9 @@ def _unambiguous(d, chunks, margin=1e-5):
         z1 = obs.double() @ w1.T + b1
         z2 = torch.nn.functional.leaky_relu(z1) @ w2.T + b2
         bad = torch.minimum(z1.abs().min(1)[0], z2.abs().min(1)[0]) < margin
-        good = torch.nonzero(~bad)[0, 0]
+        row = obs[torch.nonzero(~bad)[0, 0]].clone()
         obs = obs.clone()
-        obs[bad] = obs[good]
+        obs[bad] = row
         replaced += int(bad.sum())
         out.append((obs, act, rew, nxt, done))
     return out, replaced

@@ -69,8 +69,10 @@ if os.environ.get("PROF_DQN", "1") != "0":          # configs[4]: DQN updates of
         agent = DQN(make_args(32768, dqn_mini_batch_size=mb, replay_steps=2 * mb))
         for _ in range(mb + 2):
             agent.run()
-        for _ in range(REPS // 4 + 1):
-            agent.update()
+        for gemm in ("f16x2", "bf16x3"):                    # the default's kernels and the A/B's
+            agent.update_gemm = gemm
+            for _ in range(REPS // 4 + 1):
+                agent.update()
     torch.cuda.synchronize()
     agent.exit()
 print("done")
