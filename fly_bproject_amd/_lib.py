@@ -19,7 +19,7 @@ class FlyBuffers(C.Structure):
                                           "done_return", "done_length", "done_count")]
 
 
-ABI_VERSION = 11        # include/flyhip.h as this package binds it (fly_abi_version(): argument lists changed between versions)
+ABI_VERSION = 12        # include/flyhip.h as this package binds it (fly_abi_version(): argument lists changed between versions)
 # name -> argtypes; every entry point returns int except fly_last_error
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SYMBOLS = {
@@ -65,7 +65,7 @@ SYMBOLS = {
     "dqn_fused_h2_workspace_floats": [],
     "dqn_fused_h2_image_halves": [_L],
     "dqn_fused_update_h2": [_P] * 10 + [_I, _L, _F, _F, _P, _P, _P, _P, _I, _I, _P],
-    "dqn_adam_soft_update": [_P] * 12 + [_F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P],
+    "dqn_adam_soft_update": [_P] * 12 + [_F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P],
     "dp_p2p_alloc": [_L, C.POINTER(_P)],
     "dp_p2p_free": [_P],
     "dp_ipc_export": [_P, _P],

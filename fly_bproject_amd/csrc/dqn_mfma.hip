@@ -362,9 +362,13 @@ __global__ __launch_bounds__(DQ_ADAM_THREADS) void dqn_adam_kernel(
     const int* __restrict__ idx_f, const int* __restrict__ idx_t, const float* __restrict__ G, const float* __restrict__ mask,
     float* __restrict__ m, float* __restrict__ v, const int* __restrict__ step, float lr, float beta1, float beta2, float eps,
     float tau, u16* __restrict__ QB, u16* __restrict__ QTB, u16* __restrict__ QB_tgt, const int* __restrict__ idx_fb,
-    const int* __restrict__ idx_tb)
+    const int* __restrict__ idx_tb, const int* __restrict__ grad_invalid)
 {
     __shared__ float s_step_size, s_bc2_sqrt;
+    // fail closed: `grad_invalid` (optional) is the device word dqn_fused_update_h2 sets when a value of the update did not fit fp16 --
+    // the gradient is then not a gradient: nothing moves, the step counter stays (every block sees the same word: it is only ever
+    // set by the gradient's launches, which are done)
+    if (grad_invalid && *grad_invalid != 0) return;
     const int tid = threadIdx.x, i = blockIdx.x * DQ_ADAM_THREADS + tid;
     if (tid == 0) {
         const float ts = (float)(*step + 1);
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(DQ_ADAM_THREADS) void dqn_adam_kernel(
     }
 }
 
-__global__ void dqn_step_inc_kernel(int* step) { *step += 1; }
+__global__ void dqn_step_inc_kernel(int* step, const int* grad_invalid) { if (!(grad_invalid && *grad_invalid != 0)) *step += 1; }
 
 }  // namespace
 
@@ -478,13 +482,14 @@ extern "C" hipError_t flyhip_launch_dqn_adam(float* P, float* PF, float* PT, flo
                                              const int* idx_t, const float* G, const float* mask, float* m, float* v,
                                              int* step, float lr, float beta1, float beta2, float eps, float tau,
                                              uint16_t* QB, uint16_t* QTB, uint16_t* QB_tgt, const int* idx_fb, const int* idx_tb,
-                                             void* stream)
+                                             const int* grad_invalid, void* stream)
 {
     hipLaunchKernelGGL(dqn_adam_kernel, dim3(DQ_ADAM_BLOCKS), dim3(DQ_ADAM_THREADS), 0, (hipStream_t)stream, P, PF, PT, P_tgt,
-                       PF_tgt, idx_f, idx_t, G, mask, m, v, step, lr, beta1, beta2, eps, tau, QB, QTB, QB_tgt, idx_fb, idx_tb);
+                       PF_tgt, idx_f, idx_t, G, mask, m, v, step, lr, beta1, beta2, eps, tau, QB, QTB, QB_tgt, idx_fb, idx_tb,
+                       grad_invalid);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dqn_step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
+    hipLaunchKernelGGL(dqn_step_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, grad_invalid);
     return hipGetLastError();
 }
 

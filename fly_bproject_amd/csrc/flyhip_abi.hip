@@ -43,7 +43,7 @@ extern "C" hipError_t flyhip_launch_dqn_grad_w(const float* x, const float* h1, 
 extern "C" hipError_t flyhip_launch_dqn_adam(float* P, float* PF, float* PT, float* P_tgt, float* PF_tgt, const int* idx_f,
                                              const int* idx_t, const float* G, const float* mask, float* m, float* v,
                                              int* step, float lr, float beta1, float beta2, float eps, float tau, uint16_t* QB, uint16_t* QTB, uint16_t* QB_tgt, const int* idx_fb, const int* idx_tb,
-                                             void* stream);
+                                             const int* grad_invalid, void* stream);
 extern "C" hipError_t flyhip_p2p_alloc(int64_t n_floats, void** out);
 extern "C" hipError_t flyhip_launch_p2p_allreduce(float* G, int64_t n, void* const* bases, int rank, int world,
                                                   uint32_t epoch, int* err, int64_t fail_slot, void* stream);
@@ -175,7 +175,7 @@ int launch(FlyHandle h, int phases, const float* actions, const FlyBuffers* b, v
 extern "C" {
 
 const char* fly_last_error(void) { return g_err; }
-int fly_abi_version(void) { return 11; }
+int fly_abi_version(void) { return 12; }
 
 int fly_create(const FlyConfig* cfg, FlyHandle* out)
 {
@@ -596,7 +596,8 @@ int dqn_adam_soft_update(float* params, float* params_frag, float* params_t_frag
                          float* target_params_frag, const int32_t* idx_frag, const int32_t* idx_t_frag,
                          const float* grad, const float* mask, float* exp_avg, float* exp_avg_sq, int32_t* step,
                          float lr, float beta1, float beta2, float eps, float tau, uint16_t* params_b3, uint16_t* params_t_b3,
-                         uint16_t* target_params_b3, const int32_t* idx_b3, const int32_t* idx_t_b3, void* stream)
+                         uint16_t* target_params_b3, const int32_t* idx_b3, const int32_t* idx_t_b3, const int32_t* grad_invalid,
+                         void* stream)
 {
     if (!params || !params_frag || !params_t_frag || !target_params || !target_params_frag || !idx_frag || !idx_t_frag ||
         !grad || !mask || !exp_avg || !exp_avg_sq || !step)
@@ -605,7 +606,7 @@ int dqn_adam_soft_update(float* params, float* params_frag, float* params_t_frag
         return fail(FLY_E_ARG, "dqn_adam_soft_update: params_b3 needs params_t_b3, target_params_b3, idx_b3 and idx_t_b3");
     hipError_t e = flyhip_launch_dqn_adam(params, params_frag, params_t_frag, target_params, target_params_frag, idx_frag,
                                           idx_t_frag, grad, mask, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, tau,
-                                          params_b3, params_t_b3, target_params_b3, idx_b3, idx_t_b3, stream);
+                                          params_b3, params_t_b3, target_params_b3, idx_b3, idx_t_b3, grad_invalid, stream);
     if (e != hipSuccess) return hip_fail(e, "dqn_adam_soft_update launch");
     return FLY_OK;
 }

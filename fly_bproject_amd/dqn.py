@@ -280,6 +280,9 @@ class DQN:
         self.h2_calibrated = False          # the lagged scales have seen an update's maxima
         self.h2_freeze = False              # tests: leave the lagged scales alone (run-to-run comparisons)
         self.h2_overflows = 0               # updates whose fp16x2 gradient was refused and formed again in bf16x3
+        self._updates_issued = 0            # optimizer launches issued (the device counter packed.step lags by the refused ones)
+        self._h2_use_b3 = False             # inside _h2_poll's redo: form the gradient with the bf16x3 launches
+        self._h2_guard = False
         self._gen = torch.Generator(device=dev)
         self._gen.manual_seed(int(getattr(args, "seed", 0)))
         self._coin = torch.empty(n, device=dev)
@@ -298,7 +301,45 @@ class DQN:
         # per-tile Huber sums of every sampled step of one update (summed ONCE at its end, not per step)
         self._loss_part = torch.zeros(max(1, int(getattr(self, "mini_batch_size", 1))), r // 32, device=dev)
 
-    def _update_fused(self, chunks, inv_B):
+    def _h2_poll(self, block=False):
+        """The lazy half of the fp16x2 update's refusal path (training loop): look at overflow words copied to the host after earlier
+        updates.  A set word means: that update and every later one were refused by the optimizer launch (the word is sticky), nothing
+        moved.  Clear it, count the refused updates on the device step counter, form as many updates in bf16x3 on fresh samples of the
+        replay ring (the refused ones' samples are as good as any: replay.py:19 draws uniformly), calibrate again at the next update."""
+        pend = getattr(self, "_h2_pending", None)
+        if not pend:
+            return
+        while pend and (block or pend[0][0].query()):
+            ev, host = pend.pop(0)
+            ev.synchronize()
+            if int(host[0]) == 0:
+                continue
+            pend.clear()
+            pk = self.packed
+            pk.h2_overflow.zero_()
+            refused = self._updates_issued - int(pk.step.item())
+            self.h2_overflows += max(refused, 1)
+            self.h2_calibrated = False
+            self._h2_use_b3 = True
+            try:
+                for _ in range(refused):
+                    self._updates_issued -= 1
+                    self.update()
+            finally:
+                self._h2_use_b3 = False
+            return
+
+    def _h2_watch(self):
+        """Copy the overflow word to the host behind this update's launches (pinned, asynchronous) for a later _h2_poll."""
+        if not hasattr(self, "_h2_pending"):
+            self._h2_pending = []
+        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host.copy_(self.packed.h2_overflow, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._h2_pending.append((ev, host))
+
+    def _update_fused(self, chunks, inv_B, lazy=False):
         """The gradient of one update through `dqn_fused_update` (csrc/dqn_fused.inc): ALL sampled steps in two persistent launches
         (chain per tile with dW1 / dW3 in registers; dW2 over the saved H1 / dZ2 plane images) + one slab reduction.  bf16x3."""
         pk, lib = self.packed, self._lib
@@ -321,7 +362,7 @@ class DQN:
                              [None]) for _ in range(4)]
             self._fu_i = 0
         dev, aligned = self._fused_table(chunks)
-        if self.update_gemm == "f16x2":
+        if self.update_gemm == "f16x2" and not self._h2_use_b3:
             if not self.h2_calibrated:
                 # two passes over this update's rows that only take the class maxima (the second with the first's scales)
                 for _ in range(2):
@@ -329,7 +370,13 @@ class DQN:
                 pk.h2_overflow.zero_()
                 self.h2_calibrated = True
             loss_part = self._fused_launch_h2(dev, S, n, aligned, inv_B, 1 if self.h2_freeze else 0)
-            if int(pk.h2_overflow.item()) == 0:          # (a blocking read per update: ~15 ms of launches)
+            if lazy:
+                # the training loop: no host synchronisation here (a blocking read per env step drains the launch queue: measured
+                # ~1 ms of a 13 ms step).  The optimizer launch takes the overflow word as `grad_invalid` and refuses on the device;
+                # the word travels to the host asynchronously and is looked at when a later update begins (_h2_poll).
+                self._h2_guard = True
+                return loss_part
+            if int(pk.h2_overflow.item()) == 0:          # (explicit batches -- tests, tools: a blocking read, the answer at once)
                 return loss_part
             # some value did not fit fp16 under the scales the previous update left: nothing has been applied yet -- the bf16x3
             # launches form the same gradient with no scales at all, and the next update calibrates again
@@ -379,8 +426,12 @@ class DQN:
     def update(self, chunks=None):
         """dqn.py:64-85.  `chunks` (tests) = a list of `(obs, act, reward, next_obs, done_mask)` row blocks that
         together form the batch; default: `mini_batch_size` sampled steps of the replay ring."""
-        if chunks is None:
+        lazy = chunks is None                   # the training loop's own update: refusals are detected later (_h2_poll)
+        if lazy:
+            self._h2_poll()
             chunks = self.replay.sample(self.mini_batch_size)
+        self._updates_issued += 1
+        self._h2_guard = False
         pk, lib = self.packed, self._lib
         p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
         st = _lib.stream_ptr()
@@ -391,11 +442,14 @@ class DQN:
             for c in chunks:
                 for t in c:
                     assert t.is_contiguous() and t.dtype == torch.float32
-            loss_part = self._update_fused(chunks, inv_B)
+            loss_part = self._update_fused(chunks, inv_B, lazy)
+            guard = p(pk.h2_overflow) if self._h2_guard else None
             _lib.check(lib.dqn_adam_soft_update(p(pk.P), p(pk.PF), p(pk.PT), p(pk.P_tgt), p(pk.PF_tgt), p(pk.idx_f), p(pk.idx_t),
                                                 p(pk.G), p(pk.grad_mask), p(pk.exp_avg), p(pk.exp_avg_sq), p(pk.step),
                                                 C.c_float(self.lr), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8),
-                                                C.c_float(self.tau), *pk.plane_args(), st), "dqn_adam_soft_update")
+                                                C.c_float(self.tau), *pk.plane_args(), guard, st), "dqn_adam_soft_update")
+            if self._h2_guard:
+                self._h2_watch()
             return loss_part.sum() * inv_B
         if len(chunks) > self._loss_part.shape[0] or max(int(c[0].shape[0]) for c in chunks) > self._ws_rows:
             self.mini_batch_size = max(self.mini_batch_size, len(chunks))
@@ -415,7 +469,7 @@ class DQN:
         _lib.check(lib.dqn_adam_soft_update(p(pk.P), p(pk.PF), p(pk.PT), p(pk.P_tgt), p(pk.PF_tgt), p(pk.idx_f), p(pk.idx_t),
                                             p(pk.G), p(pk.grad_mask), p(pk.exp_avg), p(pk.exp_avg_sq), p(pk.step),
                                             C.c_float(self.lr), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8),
-                                            C.c_float(self.tau), *pk.plane_args(), st), "dqn_adam_soft_update")
+                                            C.c_float(self.tau), *pk.plane_args(), None, st), "dqn_adam_soft_update")
         return self._loss_part.sum() * inv_B                              # F.smooth_l1_loss: mean over the batch
 
     def q_parameters(self):
@@ -466,4 +520,5 @@ class DQN:
         self.run_step += 1
 
     def exit(self):
+        self._h2_poll(block=True)               # settle what the last updates left to look at
         self.env.exit()

@@ -453,6 +453,8 @@ int dqn_huber_td(const float* q_table, const float* act, const float* reward, co
  *                   streams -- online forward (DQN_QB_HALVES_ABI 16-bit words) and transposed (DQN_QTB_HALVES_ABI),
  *                   target forward -- term 0 at idx_b3[i] / idx_t_b3[i], terms 1 and 2 512 and 1024 words later
  *                   (layout: csrc/dqn_layout.h).
+ *                   FAIL CLOSED: grad_invalid != NULL and *grad_invalid != 0 (dqn_fused_update_h2's overflow word) -> nothing
+ *                   moves and the step counter stays, for this call and every later one until the host clears the word.
  */
 #define DQN_QB_HALVES_ABI 282624
 #define DQN_QTB_HALVES_ABI 221184
@@ -494,8 +496,10 @@ int dqn_fused_update(const float* params, const uint16_t* params_b3, const uint1
  *   h2_scales    device float [MLP_H2_SCALE_FLOATS_ABI]: s[c] at [c], 1 / s[c] at [16 + c], the last call's maximum of |scaled value|
  *                at [32 + c]; classes 0 X, 1 H1, 2 H2, 5 dZ2, 6 dZ1 (lagged), 8 .. 10 / 11 .. 13 online / target W1 .. W3 (exact, per
  *                call).  Start it at 1.0 / 1.0 / 0 and run two calls with flags = 2 on the first update's chunks.
- *   h2_overflow  device int: set to 1 when a value of THIS call did not fit fp16 under the lagged scales -- `grad` is then invalid:
- *                clear the word, form the gradient with dqn_fused_update (bf16x3; nothing has been applied yet) and calibrate again.
+ *   h2_overflow  device int: set to 1 when a value of THIS call did not fit fp16 under the lagged scales -- `grad` is then invalid.
+ *                Either read it before the optimizer launch (clear it, form the gradient with dqn_fused_update -- bf16x3; nothing has
+ *                been applied yet -- and calibrate again), or hand it to dqn_adam_soft_update as grad_invalid and look later: the
+ *                optimizer then refuses every update until the word is cleared (the device step counter says how many).
  *   flags        bit 0: leave the lagged scales unchanged; bit 1: calibration pass (class maxima -> scales only; `grad` not written).
  * `workspace`: dqn_fused_h2_workspace_floats() floats; `images`: dqn_fused_h2_image_halves(num_chunks * n) 16-bit words. */
 #define DQN_QH_HALVES_ABI 188416
@@ -512,7 +516,7 @@ int dqn_adam_soft_update(float* params, float* params_frag, float* params_t_frag
                          const float* grad, const float* mask, float* exp_avg, float* exp_avg_sq, int32_t* step,
                          float lr, float beta1, float beta2, float eps, float tau, uint16_t* params_b3,
                          uint16_t* params_t_b3, uint16_t* target_params_b3, const int32_t* idx_b3,
-                         const int32_t* idx_t_b3, void* stream);
+                         const int32_t* idx_t_b3, const int32_t* grad_invalid, void* stream);
 
 
 /*

@@ -80,6 +80,7 @@ def _bare_dqn(golden_sd=None, rows=384, fused=False, gemm="f16x2"):
     d._alloc_workspace(rows)
     d.fused_update = fused
     d.update_gemm, d.h2_calibrated, d.h2_freeze, d.h2_overflows = gemm, False, False, 0
+    d._updates_issued, d._h2_use_b3, d._h2_guard = 0, False, False
     return d
 
 

@@ -207,3 +207,43 @@ def test_h2_update_is_independent_of_the_grid():
     m = d.packed.grad_mask > 0
     assert float((acc - g_a)[m].abs().max()) <= 2e-5 * float(g_a[m].abs().max())
     assert d.h2_overflows == 0
+
+
+def test_h2_overflow_in_the_training_loop_is_refused_on_the_device_and_settled_later():
+    """`DQN.run()`'s own updates do not synchronise with the host (a blocking read per env step drains the launch queue): the optimizer
+    launch takes the overflow word as `grad_invalid`, the host looks at a copy of it when a later update begins.  A lagged scale pushed
+    2^14 too high between two env steps: the updates from there on are refused ON THE DEVICE (nothing moves, the step counter stays),
+    the host finds out within the next steps, clears the word, forms as many updates in bf16x3 and goes on in fp16x2 -- at the end every
+    env step has had its update and the networks are finite."""
+    import contextlib
+    import io
+    from fly_bproject_amd.dqn import DQN
+    from tests.hip_helpers import make_args
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        agent = DQN(make_args(256, dqn_mini_batch_size=8, replay_steps=16))
+        for _ in range(14):
+            agent.run()
+    torch.cuda.synchronize()
+    assert agent.update_gemm == "f16x2" and agent.h2_calibrated and agent.h2_overflows == 0
+    issued0 = agent._updates_issued
+    assert issued0 == 14 - 8 and int(agent.packed.step) == issued0
+    p_before = agent.packed.P.clone()
+    with torch.no_grad():
+        agent.packed.h2_scales[0] *= 2.0 ** 14
+        agent.packed.h2_scales[16] /= 2.0 ** 14
+    with contextlib.redirect_stdout(io.StringIO()):
+        agent.run()                                      # this update overflows: refused on the device
+    torch.cuda.synchronize()
+    assert int(agent.packed.h2_overflow) == 1 and int(agent.packed.step) == issued0 and torch.equal(agent.packed.P, p_before)
+    with contextlib.redirect_stdout(io.StringIO()):
+        for _ in range(4):
+            agent.run()                                  # the host notices, redoes the refused updates in bf16x3, calibrates, goes on
+        agent._h2_poll(block=True)                       # (at the latest here)
+        agent.run()                                      # and an fp16x2 update again: calibrates first
+        agent._h2_poll(block=True)
+    torch.cuda.synchronize()
+    assert agent.h2_overflows >= 1 and int(agent.packed.h2_overflow) == 0 and agent.h2_calibrated
+    assert agent._updates_issued == issued0 + 6 and int(agent.packed.step) == issued0 + 6
+    assert not torch.equal(agent.packed.P, p_before) and all(torch.isfinite(q).all() for q in agent.q.parameters())
+    agent.exit()

@@ -25,7 +25,7 @@ def lib():
 
 def test_library_is_the_hip_build(lib):
     l = lib.load()
-    assert l.fly_abi_version() == lib.ABI_VERSION == 11
+    assert l.fly_abi_version() == lib.ABI_VERSION == 12
     assert torch.cuda.is_available() and "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
 
 

@@ -74,6 +74,12 @@ fine = np.array([[s[b, t, 18] - s[b, t, 12], s[b, t, 17] - s[b, t, 18], s[b, t, 
                  for b in range(grid) for t in range(per) if s[b, t, 11] > 0])
 print("   column tile 0: x DMA issue + H1/dZ2 fragment reads + dW2 c = 0..3 %.0f | c = 4..7 %.0f | fragment assembly, db2, drain, head of the second GEMM %.0f || column tile 1: GEMM %.0f | dW2 + epilogue %.0f"
       % tuple(fine.mean(0)))
+if len(sys.argv) > 2 and sys.argv[2] == "f16x2":      # finer inside column tile 0's dW2 (the fp16x2 instantiation stamps them)
+    ff = np.array([[s[b, t, 19] - s[b, t, 12], s[b, t, 20] - s[b, t, 19], s[b, t, 21] - s[b, t, 20], s[b, t, 22] - s[b, t, 21], s[b, t, 23] - s[b, t, 22],
+                    s[b, t, 18] - s[b, t, 23]] for b in range(grid) for t in range(per) if s[b, t, 11] > 0 and s[b, t, 19] > 0])
+    if len(ff):
+        print("   column tile 0, finer: x DMA issue %.0f | fragment reads issued %.0f | c = 0: its three products %.0f | c = 0: db2 products + settle %.0f | c = 1 %.0f | c = 2, 3 %.0f"
+              % tuple(ff.mean(0)))
 tail = s[:, 63, 1] - s[:, 63, 0]
 print("epilogue (slab write + bias sums) per workgroup: mean %.0f cycles" % tail.mean())
 pro = s[:, 62, 2] - s[:, 62, 0]
