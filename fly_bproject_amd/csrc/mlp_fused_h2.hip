@@ -48,6 +48,7 @@ extern "C" hipError_t flyhip_launch_mlp_fused_grad_h2(const float* P, const uint
     const int ovr = flyhip_debug_get_fused_grid();
     if (ovr > 0 && ovr < grid) grid = ovr;
     const long tiles = (n + BM - 1) / BM;
+    if (tiles + 4096 >= (1L << 31)) return hipErrorInvalidValue;        // the kernel counts tiles in 32 bits
     if (tiles < grid) grid = (int)tiles;
     FusedDump d = {};
     const int mode = dump == nullptr ? 0 : (dump[1] == nullptr ? 2 : 1);
