@@ -564,7 +564,8 @@ extern "C" int64_t flyhip_dqn_fused_h2_workspace_floats(void) { return (int64_t)
 extern "C" int64_t flyhip_dqn_fused_h2_image_halves(int64_t rows) { return (rows / BM) * 2 * (int64_t)DH_IMAGE_HALVES; }
 
 // flags: bit 0 = leave the lagged scales as they are (tests: run-to-run comparisons), bit 1 = calibration pass (no dW2, no
-// reduction: only the class maxima -> scales; `grad` is not written)
+// reduction: only the class maxima -> scales; `grad` is not written), bit 2 = dZ2's image stays home: the chain kernel leaves a
+// 2304-byte record per tile in its place and dqn_dw2r_h2_kernel rebuilds dZ2 from it (dqn_fused_h2.inc)
 extern "C" hipError_t flyhip_launch_dqn_fused_update_h2(const float* P, uint16_t* QH, uint16_t* QTH, const float* P_tgt, uint16_t* QH_tgt,
                                                         const int* idx_fb, const int* idx_tb, float* fsc, int* ovf, const void* chunks,
                                                         int S, int64_t n, float discount, float inv_B, uint16_t* images, float* workspace,
@@ -580,6 +581,8 @@ extern "C" hipError_t flyhip_launch_dqn_fused_update_h2(const float* P, uint16_t
         if (ea != hipSuccess) return ea;
         ea = hipFuncSetAttribute(reinterpret_cast<const void*>(dqn_dw2_h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW2H_LDS_BYTES);
         if (ea != hipSuccess) return ea;
+        ea = hipFuncSetAttribute(reinterpret_cast<const void*>(dqn_dw2r_h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW2R_LDS_BYTES);
+        if (ea != hipSuccess) return ea;
     }
     float* ws1 = workspace;
     float* ws2 = ws1 + (long)cus * DF_STRIDE1;
@@ -592,13 +595,16 @@ extern "C" hipError_t flyhip_launch_dqn_fused_update_h2(const float* P, uint16_t
     if (g_dqn_phases & 1) {
         hipLaunchKernelGGL(dqn_chain_h2_kernel, dim3(grid), dim3(THREADS), DH_LDS_BYTES, st, P, QH, QTH, P_tgt, QH_tgt, fsc,
                            static_cast<const DqnChunk*>(chunks), S, tiles_per, discount, inv_B, images, ws1, ws2, ws3, wsmax, loss_part,
-                           g_dqn_stamps, rows_aligned16);
+                           g_dqn_stamps, rows_aligned16, (flags & 4) ? 1 : 0);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
     if (!(flags & 2)) {
         if (g_dqn_phases & 2) {
-            hipLaunchKernelGGL(dqn_dw2_h2_kernel, dim3(grid), dim3(THREADS), DW2H_LDS_BYTES, st, images, ntiles, fsc, ws2);
+            if (flags & 4)
+                hipLaunchKernelGGL(dqn_dw2r_h2_kernel, dim3(grid), dim3(THREADS), DW2R_LDS_BYTES, st, images, ntiles, P, fsc, ws2);
+            else
+                hipLaunchKernelGGL(dqn_dw2_h2_kernel, dim3(grid), dim3(THREADS), DW2H_LDS_BYTES, st, images, ntiles, fsc, ws2);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
         }

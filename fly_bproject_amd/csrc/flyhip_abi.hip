@@ -660,7 +660,7 @@ int dqn_fused_update_h2(const float* params, uint16_t* params_h2, uint16_t* para
     if (!(inv_B > 0.0f) || !(inv_B < 1.0e30f)) return fail(FLY_E_ARG, "dqn_fused_update_h2: inv_B must be a positive finite number");
     hipError_t e = flyhip_launch_dqn_fused_update_h2(params, params_h2, params_t_h2, target_params, target_params_h2, idx_b3, idx_t_b3,
                                                      h2_scales, h2_overflow, chunks, num_chunks, n, discount, inv_B, images, workspace, grad,
-                                                     loss_part, rows_aligned16 ? 1 : 0, flags & 3, stream);
+                                                     loss_part, rows_aligned16 ? 1 : 0, flags & 7, stream);
     if (e != hipSuccess) return hip_fail(e, "dqn_fused_update_h2 launch");
     return FLY_OK;
 }

@@ -277,6 +277,9 @@ class DQN:
         if gemm not in ("f16x2", "bf16x3"):
             raise ValueError("dqn_gemm / FLY_DQN_GEMM must be f16x2 or bf16x3, not %r" % (gemm,))
         self.update_gemm = gemm
+        # dZ2's plane image stays home (flags bit 2 of dqn_fused_update_h2: the dW2 kernel rebuilds dZ2 from a 2.3 KB record per tile);
+        # FLY_DQN_DW2_RECON=0 keeps the image (the first form, the A/B)
+        self.dw2_recon = os.environ.get("FLY_DQN_DW2_RECON", "1") != "0"
         self.h2_calibrated = False          # the lagged scales have seen an update's maxima
         self.h2_freeze = False              # tests: leave the lagged scales alone (run-to-run comparisons)
         self.h2_overflows = 0               # updates whose fp16x2 gradient was refused and formed again in bf16x3
@@ -420,7 +423,7 @@ class DQN:
         _lib.check(lib.dqn_fused_update_h2(p(pk.P), p(pk.QH), p(pk.QTH), p(pk.P_tgt), p(pk.QH_tgt), p(pk.idx_fb), p(pk.idx_tb),
                                            p(pk.h2_scales), p(pk.h2_overflow), p(dev), C.c_int(S), C.c_int64(n), C.c_float(self.discount),
                                            C.c_float(inv_B), p(self._fu_images), p(self._fu_ws), p(pk.G), p(loss_part), C.c_int(aligned),
-                                           C.c_int(flags), _lib.stream_ptr()), "dqn_fused_update_h2")
+                                           C.c_int(flags | (4 if getattr(self, "dw2_recon", False) else 0)), _lib.stream_ptr()), "dqn_fused_update_h2")
         return loss_part
 
     def update(self, chunks=None):

@@ -501,6 +501,8 @@ int dqn_fused_update(const float* params, const uint16_t* params_b3, const uint1
  *                been applied yet -- and calibrate again), or hand it to dqn_adam_soft_update as grad_invalid and look later: the
  *                optimizer then refuses every update until the word is cleared (the device step counter says how many).
  *   flags        bit 0: leave the lagged scales unchanged; bit 1: calibration pass (class maxima -> scales only; `grad` not written).
+ *                bit 2: dZ2's plane image is not written: the chain kernel leaves a 2304-byte record per tile (dq s_z2 and the action per
+ *                row, LeakyReLU' flags) and the dW2 kernel rebuilds dZ2 from it and the fp32 W3 rows of `params` (a third less image traffic).
  * `workspace`: dqn_fused_h2_workspace_floats() floats; `images`: dqn_fused_h2_image_halves(num_chunks * n) 16-bit words. */
 #define DQN_QH_HALVES_ABI 188416
 #define DQN_QTH_HALVES_ABI 147456

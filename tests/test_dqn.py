@@ -81,6 +81,8 @@ def _bare_dqn(golden_sd=None, rows=384, fused=False, gemm="f16x2"):
     d.fused_update = fused
     d.update_gemm, d.h2_calibrated, d.h2_freeze, d.h2_overflows = gemm, False, False, 0
     d._updates_issued, d._h2_use_b3, d._h2_guard = 0, False, False
+    import os
+    d.dw2_recon = os.environ.get("FLY_DQN_DW2_RECON", "1") != "0"      # (DQN.__init__'s switch: the suite runs under either setting)
     return d
 
 

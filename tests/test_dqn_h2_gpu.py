@@ -247,3 +247,34 @@ def test_h2_overflow_in_the_training_loop_is_refused_on_the_device_and_settled_l
     assert agent._updates_issued == issued0 + 6 and int(agent.packed.step) == issued0 + 6
     assert not torch.equal(agent.packed.P, p_before) and all(torch.isfinite(q).all() for q in agent.q.parameters())
     agent.exit()
+
+
+def test_h2_dw2_from_the_record_against_the_image_form_and_float64():
+    """The default dW2 kernel rebuilds dZ2 from a 2.3 KB record per tile (dq s_z2 and the action per row, LeakyReLU' flags) instead of
+    reading its 32 KB plane image: the layer-2 weight gradient of both forms against float64 (<= 2e-6 of its scale each: the rebuilt
+    dZ2 is the correctly rounded fp32 product, the image a two-term fp16 split of the chain's) and against each other; every other
+    block of the gradient bit-equal (only `dqn_dw2` differs); 5 x 4096 rows: workgroups walk tiles across chunk boundaries."""
+    torch.manual_seed(12)
+    raw = _batch(5, 4096, 31)
+    d = _bare_dqn(rows=4096, fused=True)
+    _perturb_target(d)
+    chunks, _ = _unambiguous(d, raw)
+    want, _ = _grad64(d, chunks)
+    st = _state(d)
+    d.update(chunks); _restore(d, st)                    # calibrated
+    d.h2_freeze = True
+    got = {}
+    for recon in (True, False):
+        d.dw2_recon = recon
+        d.update(chunks); torch.cuda.synchronize()
+        got[recon] = d.packed.G.clone()
+        _restore(d, st)
+    w2 = want[2]
+    scale = float(w2.abs().max())
+    for recon in (True, False):
+        g2 = _views(got[recon])[2].double()
+        assert float((g2 - w2).abs().max()) <= 2e-6 * scale, recon
+    a, b = got[True].clone(), got[False].clone()
+    assert float((_views(a)[2] - _views(b)[2]).abs().max()) <= 2e-6 * scale and not torch.equal(_views(a)[2], _views(b)[2])
+    _views(a)[2].zero_(); _views(b)[2].zero_()
+    assert torch.equal(a, b)
