@@ -764,13 +764,15 @@ def dqn_measure(n, mb, warmup, steps, kernel_reps, gemm=None):
         lib.flyhip_debug_set_dqn_fused_phases(7)
         agent.packed.h2_overflow.zero_()
         peak = mlp_peak_for("f16x2" if h2 else "bf16x3")
-        kn = ("dqn_chain_h2_kernel", "dqn_dw2_h2_kernel") if h2 else ("dqn_chain_kernel", "dqn_dw2_kernel")
+        kn = ("dqn_chain_h2_kernel", "dqn_dw2r_h2_kernel" if getattr(agent, "dw2_recon", False) else "dqn_dw2_h2_kernel") if h2 \
+            else ("dqn_chain_kernel", "dqn_dw2_kernel")
         rows = n * mb
         dw13 = 2 * (73 * 256 + 256 * 18)                                   # dW1 + dW3 per row
         ks = [mfma(kn[0] + " (per 32-row tile: target fwd, online fwd, Huber-TD, dX chain, dW1 / dW3 / db in registers; "
                    "%d rows = one update%s)" % (rows, "; with dqn_h2_scales_kernel behind it" if h2 else ""),
                    t["chain"], (2 * DQN_FWD_FLOP + DQN_BWD_DX_FLOP + dw13) * rows, 1, peak),
-              mfma(kn[1] + " (dW2 over the saved H1 | dZ2 plane images)", t["dw2"], 2 * 256 * 256 * rows, 1, peak),
+              mfma(kn[1] + (" (dW2 over the saved H1 plane image, dZ2 rebuilt from a 2.3 KB record per tile)" if kn[1].startswith("dqn_dw2r")
+                            else " (dW2 over the saved H1 | dZ2 plane images)"), t["dw2"], 2 * 256 * 256 * rows, 1, peak),
               {"kernel": "dqn_grad_reduce_kernel (fixed-order sum of the per-CU slabs)", "avg_launch_us": round(t["reduce"] * 1e6, 3),
                "launches_per_step": 1, "step_share_ms": round(t["reduce"] * 1e3, 3)},
               mfma("dqn_act_kernel (forward + argmax + eps-greedy)", t_act, DQN_FWD_FLOP * n, 1)]

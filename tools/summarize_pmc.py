@@ -19,7 +19,7 @@ import re
 import sys
 
 WIDE_READS = ("mlp_fused_step_kernel", "mlp_fused_step_h2_kernel", "mlp_grad_reduce_h2_kernel", "mlp_forward_kernel", "mlp_backward_dx_kernel", "mlp_fwd_bwd_kernel", "mlp_grad_w_kernel", "mlp_grad_w_b3_kernel",
-              "mlp_grad_reduce_kernel", "dqn_td_kernel", "dqn_grad_w_kernel", "dqn_grad_reduce_kernel", "dqn_forward_kernel", "dqn_act_kernel", "dqn_chain_kernel", "dqn_dw2_kernel", "dqn_chain_h2_kernel", "dqn_dw2_h2_kernel")
+              "mlp_grad_reduce_kernel", "dqn_td_kernel", "dqn_grad_w_kernel", "dqn_grad_reduce_kernel", "dqn_forward_kernel", "dqn_act_kernel", "dqn_chain_kernel", "dqn_dw2_kernel", "dqn_chain_h2_kernel", "dqn_dw2_h2_kernel", "dqn_dw2r_h2_kernel")
 
 
 def short(name):
@@ -61,7 +61,7 @@ def main():
         mult = 2.0 if key.split("@")[0] in WIDE_READS else 1.0
         t["read_correction"] = mult
         t["hbm_bytes_per_launch"] = int((t["fetch_kib"] * mult + t["write_kib"]) * 1024)
-        if key.split("@")[0] in ("dqn_chain_kernel", "dqn_dw2_kernel", "dqn_chain_h2_kernel", "dqn_dw2_h2_kernel"):     # one launch per UPDATE: prof_kernels.py's PROF_DQN_MB sampled steps
+        if key.split("@")[0] in ("dqn_chain_kernel", "dqn_dw2_kernel", "dqn_chain_h2_kernel", "dqn_dw2_h2_kernel", "dqn_dw2r_h2_kernel"):     # one launch per UPDATE: prof_kernels.py's PROF_DQN_MB sampled steps
             t["sampled_steps_per_launch"] = int(os.environ.get("PROF_DQN_MB", "4"))
             t["hbm_bytes_per_sampled_step"] = t["hbm_bytes_per_launch"] // t["sampled_steps_per_launch"]
     with open(os.path.join(out_dir, "%s_traffic.json" % tag), "w") as fo:
