@@ -727,6 +727,7 @@ def dqn_measure(n, mb, warmup, steps, kernel_reps, gemm=None):
     elapsed = time.perf_counter() - t0
     assert int(agent.packed.step.item()) == warmup + steps, "an update was skipped"
     h2_refused = int(agent.h2_overflows)
+    recon_form = bool(getattr(agent, "dw2_recon", False))
     finite = all(torch.isfinite(p).all().item() for p in agent.q.parameters())
     lib = _lib.load()
     p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
@@ -814,8 +815,9 @@ def dqn_measure(n, mb, warmup, steps, kernel_reps, gemm=None):
         "metric": "env-steps/sec (DQN act + env step + update), %d envs" % n, "value": round(n * steps / elapsed, 1),
         "unit": "env-steps/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-        "update_path": (("dqn_fused_update_h2 (fp16x2 chain + dW2 over two-plane images; %d of the run's updates refused and formed again in bf16x3)"
-                         % h2_refused) if dtype == "f16x2" else "dqn_fused_update (bf16x3 chain + dW2 over plane images)") if fused
+        "update_path": (("dqn_fused_update_h2 (fp16x2 chain + dW2 over H1's two-plane image, dZ2 %s; %d of the run's updates refused and formed "
+                         "again in bf16x3)" % ("rebuilt from a 2.3 KB record per tile" if recon_form else "from its image", h2_refused))
+                        if dtype == "f16x2" else "dqn_fused_update (bf16x3 chain + dW2 over plane images)") if fused
                        else "dqn_td_step + dqn_grad_w per sampled step (fp32 MFMA)",
         "config": {"workload": "fly_dqn_%denvs_batch%dsteps" % (n, mb), "num_envs_per_gpu": n, "sampled_steps_per_update": mb,
                    "rows_per_update": n * mb, "replay_capacity_steps": capacity, "replay_bytes": rbytes,
